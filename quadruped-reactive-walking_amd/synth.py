@@ -1,0 +1,258 @@
+"""Synthetic Solo12 control-loop inputs for tests and bench (host side, numpy).
+
+Recipe: SURVEY.md §8(d).  Per instance b the RNG seed is 20260000 + b.  The shapes and
+formulas follow the reference components that produce the hot path's inputs:
+  - gait rows            src/Gait.cpp:38-108 (walk / trot / pacing / bounding / static)
+  - reference trajectory src/StatePlanner.cpp:21-61 (computeReferenceStates)
+  - footstep matrix      src/FootstepPlanner.cpp:76-186 (computeFootsteps / computeNextFootstep)
+  - velocity ranges      scripts/Joystick.py:201-284
+  - WBC call assembly    scripts/Controller.py:275-303
+This is an input generator, not a re-implementation of the planners: it keeps no
+persistent footstep state (feet in stance at row 0 are placed analytically).
+"""
+import numpy as np
+
+SHOULDERS = np.array([[0.1946, 0.1946, -0.1946, -0.1946],
+                      [0.14695, -0.14695, 0.14695, -0.14695],
+                      [0.0, 0.0, 0.0, 0.0]])  # scripts/Controller.py:131-133
+Q_NOMINAL = np.array([0.0, 0.7, -1.4, 0.0, 0.7, -1.4, 0.0, -0.7, 1.4, 0.0, -0.7, 1.4])  # scripts/test_mpc.py:40
+H_REF = 0.2229  # 0.32*cos(0.8), scripts/Estimator.py:245
+GAIT_KINDS = ("trot", "walk", "bounding", "pacing", "static")
+
+
+def gait_pattern(kind, n_period):
+    """One period of contact rows (n_period x 4), src/Gait.cpp:38-108."""
+    P = np.zeros((n_period, 4))
+    if kind == "trot":
+        h = n_period // 2
+        P[:h] = [1, 0, 0, 1]
+        P[h:] = [0, 1, 1, 0]
+    elif kind == "pacing":
+        h = n_period // 2
+        P[:h] = [1, 0, 1, 0]
+        P[h:] = [0, 1, 0, 1]
+    elif kind == "bounding":
+        h = n_period // 2
+        P[:h] = [1, 1, 0, 0]
+        P[h:] = [0, 0, 1, 1]
+    elif kind == "walk":
+        qn = n_period // 4
+        seqs = ([0, 1, 1, 1], [1, 0, 1, 1], [1, 1, 0, 1], [1, 1, 1, 0])
+        for i, s in enumerate(seqs):
+            P[i * qn:(i + 1) * qn] = s
+        P[4 * qn:] = seqs[3]
+    elif kind == "static":
+        P[:] = 1
+    else:
+        raise ValueError(kind)
+    return P
+
+
+def reference_states(x0, vref, n_steps, dt, h_ref=H_REF):
+    """xref (B,12,N+1): column 0 = current state, columns 1.. per src/StatePlanner.cpp:35-60."""
+    x0 = np.atleast_2d(x0)
+    vref = np.atleast_2d(vref)
+    B = x0.shape[0]
+    xref = np.zeros((B, 12, n_steps + 1))
+    xref[:, :, 0] = x0
+    t = dt * np.arange(1, n_steps + 1)[None, :]
+    vx, vy, wz = vref[:, 0:1], vref[:, 1:2], vref[:, 5:6]
+    nz = (wz != 0)
+    wsafe = np.where(nz, wz, 1.0)
+    xs = np.where(nz, (vx * np.sin(wz * t) + vy * (np.cos(wz * t) - 1.0)) / wsafe, vx * t)
+    ys = np.where(nz, (vy * np.sin(wz * t) - vx * (np.cos(wz * t) - 1.0)) / wsafe, vy * t)
+    xref[:, 0, 1:] = xs + x0[:, 0:1]
+    xref[:, 1, 1:] = ys + x0[:, 1:2]
+    xref[:, 2, 1:] = h_ref
+    yaw = wz * t
+    xref[:, 5, 1:] = yaw
+    xref[:, 6, 1:] = vx * np.cos(yaw) - vy * np.sin(yaw)
+    xref[:, 7, 1:] = vx * np.sin(yaw) + vy * np.cos(yaw)
+    xref[:, 11, 1:] = wz
+    return xref
+
+
+def footsteps(gait, v, vref, n_steps, dt, progress0, h_ref=H_REF, k_feedback=0.03, L=0.155, g=9.81):
+    """fsteps (B,N_gait,12) from gait (B,N_gait,4): zero for swing feet and beyond the horizon.
+
+    Future touch-downs follow src/FootstepPlanner.cpp:113-186; a foot already in stance at row 0
+    is placed where a foot `progress0` (B,4) through its stance would be (in the base frame).
+    """
+    B, N_gait, _ = gait.shape
+    fs = np.zeros((B, N_gait, 12))
+    # stance duration per foot: count of 1s in a period (src/Gait.cpp getPhaseDuration semantics)
+    t_stance = dt * gait[:, :n_steps, :].sum(axis=1)  # (B,4)
+    t_stance = np.where(t_stance <= 0, dt * n_steps, t_stance)
+    t_stance = np.minimum(t_stance, dt * n_steps)
+    cross = np.stack([v[:, 1] * vref[:, 5] - v[:, 2] * vref[:, 4], v[:, 2] * vref[:, 3] - v[:, 0] * vref[:, 5]], 1)
+    dt_cum = dt * np.arange(N_gait)[None, :] * np.ones((B, 1))
+    wz = vref[:, 5:6]
+    nz = (wz != 0)
+    wsafe = np.where(nz, wz, 1.0)
+    dx = np.where(nz, (v[:, 0:1] * np.sin(wz * dt_cum) + v[:, 1:2] * (np.cos(wz * dt_cum) - 1.0)) / wsafe,
+                  v[:, 0:1] * dt_cum)
+    dy = np.where(nz, (v[:, 1:2] * np.sin(wz * dt_cum) - v[:, 0:1] * (np.cos(wz * dt_cum) - 1.0)) / wsafe,
+                  v[:, 1:2] * dt_cum)
+    yaws = wz * dt_cum
+    for j in range(4):
+        nxt = np.zeros((B, 2))
+        for c in range(2):
+            off = t_stance[:, j] * 0.5 * v[:, c] + k_feedback * (v[:, c] - vref[:, c]) \
+                + 0.5 * np.sqrt(h_ref / g) * cross[:, c]
+            nxt[:, c] = np.clip(off, -L, L) + SHOULDERS[c, j]
+        cur = np.zeros((B, 2))
+        for c in range(2):
+            cur[:, c] = SHOULDERS[c, j] + (0.5 - progress0[:, j]) * t_stance[:, j] * v[:, c]
+        pos = np.zeros((B, 2))
+        st0 = gait[:, 0, j] > 0
+        pos[st0] = cur[st0]
+        fs[:, 0, 3 * j:3 * j + 2] = np.where(st0[:, None], pos, 0.0)
+        for i in range(1, n_steps):
+            st = gait[:, i, j] > 0
+            was = gait[:, i - 1, j] > 0
+            new = st & ~was
+            c_, s_ = np.cos(yaws[:, i - 1]), np.sin(yaws[:, i - 1])
+            px = c_ * nxt[:, 0] - s_ * nxt[:, 1] + dx[:, i - 1]
+            py = s_ * nxt[:, 0] + c_ * nxt[:, 1] + dy[:, i - 1]
+            pos = np.where(new[:, None], np.stack([px, py], 1), pos)
+            fs[:, i, 3 * j:3 * j + 2] = np.where(st[:, None], pos, 0.0)
+    # a stance foot whose x happens to be exactly 0 would read as swing (src/MPC.cpp:691)
+    x = fs[:, :, 0::3]
+    fs[:, :, 0::3] = np.where((gait > 0) & (x == 0.0), 1e-9, x)
+    return fs
+
+
+def leg_fk(qj):
+    """Foot positions (B,4,3) of the fixed-base Solo12 (constants of include/qrw_solo12_model.h)."""
+    qj = np.atleast_2d(qj)
+    B = qj.shape[0]
+    out = np.zeros((B, 4, 3))
+    sx = [1, 1, -1, -1]
+    sy = [1, -1, 1, -1]
+    for leg in range(4):
+        q0, q1, q2 = qj[:, 3 * leg], qj[:, 3 * leg + 1], qj[:, 3 * leg + 2]
+        foot = np.array([0.0, sy[leg] * 0.008, -0.16])
+        kfe = np.array([0.0, sy[leg] * 0.03745, -0.16])
+        hfe = np.array([0.0, sy[leg] * 0.014, 0.0])
+        haa = np.array([sx[leg] * 0.1946, sy[leg] * 0.0875, 0.0])
+
+        def ry(a, p):
+            return np.stack([np.cos(a) * p[..., 0] + np.sin(a) * p[..., 2], p[..., 1] + 0 * a,
+                             -np.sin(a) * p[..., 0] + np.cos(a) * p[..., 2]], -1)
+
+        def rx(a, p):
+            return np.stack([p[..., 0] + 0 * a, np.cos(a) * p[..., 1] - np.sin(a) * p[..., 2],
+                             np.sin(a) * p[..., 1] + np.cos(a) * p[..., 2]], -1)
+
+        p = ry(q2, np.broadcast_to(foot, (B, 3))) + kfe
+        p = ry(q1, p) + hfe
+        p = rx(q0, p) + haa
+        out[:, leg] = p
+    return out
+
+
+class SyntheticBatch:
+    """Deterministic batched input sequences.
+
+    step(s) returns a dict with the MPC inputs of receding-horizon call s
+    (xref (B,12,N+1), fsteps (B,N_gait,12), gait (B,N_gait,4)) and the WBC inputs of the
+    same control step (q (B,19), dq (B,18), contacts (B,4), pgoals/vgoals/agoals (B,3,4)).
+    x0 may be supplied to close the loop with the MPC's predicted next state
+    (scripts/test_mpc.py:78); otherwise the state follows the reference plus noise.
+    """
+
+    def __init__(self, B, n_steps=16, N_gait=20, dt=0.02, gaits=("trot",), n_seq=64, seed0=20260000, b0=0):
+        self.B, self.N, self.N_gait, self.dt = B, n_steps, N_gait, dt
+        self.n_seq = n_seq
+        self.vref = np.zeros((B, 6))
+        self.phase = np.zeros(B, dtype=np.int64)
+        self.kind = np.zeros(B, dtype=np.int64)
+        self.noise_x0 = np.zeros((n_seq, B, 12))
+        self.noise_q = np.zeros((n_seq, B, 12))
+        self.noise_dq = np.zeros((n_seq, B, 12))
+        self.noise_goal = np.zeros((n_seq, B, 3, 4, 3))
+        self.gaits = tuple(gaits)
+        for b in range(B):
+            r = np.random.default_rng(seed0 + b0 + b)
+            self.vref[b, 0] = r.uniform(-0.5, 1.5)
+            self.vref[b, 1] = r.uniform(-0.5, 0.5)
+            self.vref[b, 5] = r.uniform(-0.7, 0.7)
+            self.phase[b] = r.integers(0, n_steps)
+            self.kind[b] = r.integers(0, len(self.gaits))
+            nx = r.uniform(-1, 1, (n_seq, 12))
+            nx *= np.array([0, 0, 0.01, 0.05, 0.05, 0, 0.1, 0.1, 0.1, 0.2, 0.2, 0.2])
+            self.noise_x0[:, b] = nx
+            self.noise_q[:, b] = r.uniform(-0.1, 0.1, (n_seq, 12))
+            self.noise_dq[:, b] = r.uniform(-1.0, 1.0, (n_seq, 12))
+            self.noise_goal[:, b] = r.uniform(-1.0, 1.0, (n_seq, 3, 4, 3))
+        self.patterns = [gait_pattern(k, n_steps) for k in self.gaits]
+
+    def gait_at(self, s):
+        B, N = self.B, self.N
+        gait = np.zeros((B, self.N_gait, 4))
+        rows = (self.phase[:, None] + s + np.arange(N)[None, :]) % N
+        for ki, P in enumerate(self.patterns):
+            m = self.kind == ki
+            if m.any():
+                gait[m, :N] = P[rows[m]]
+        return gait
+
+    def progress_at(self, s, gait):
+        """fraction of its stance each row-0 stance foot has completed (0 for swing feet)."""
+        B, N = self.B, self.N
+        prog = np.zeros((B, 4))
+        for ki, P in enumerate(self.patterns):
+            m = np.where(self.kind == ki)[0]
+            if m.size == 0:
+                continue
+            for j in range(4):
+                col = P[:, j]
+                # for each row of the period: (#consecutive stance rows before it, stance length)
+                before = np.zeros(N)
+                length = np.zeros(N)
+                for r in range(N):
+                    if col[r] > 0:
+                        k = 0
+                        while k < N and col[(r - k - 1) % N] > 0:
+                            k += 1
+                        a = 0
+                        while a < N and col[(r + a) % N] > 0:
+                            a += 1
+                        before[r], length[r] = min(k, N), min(k + a, N)
+                r0 = (self.phase[m] + s) % N
+                prog[m, j] = np.where(length[r0] > 0, before[r0] / np.maximum(length[r0], 1), 0.0)
+        return prog
+
+    def step(self, s, x0=None):
+        B, N, dt = self.B, self.N, self.dt
+        i = s % self.n_seq
+        base = np.zeros((B, 12))
+        base[:, 2] = H_REF
+        base[:, 6:9] = self.vref[:, 0:3]
+        base[:, 9:12] = self.vref[:, 3:6]
+        if x0 is None:
+            x0 = base + self.noise_x0[i]
+        else:
+            x0 = np.array(x0, dtype=np.float64).reshape(B, 12).copy()
+            x0[:, 0:2] = 0.0  # horizontal frame, src/StatePlanner.cpp:27-31
+            x0[:, 5] = 0.0
+        xref = reference_states(x0, self.vref, N, dt)
+        gait = self.gait_at(s)
+        fsteps = footsteps(gait, x0[:, 6:12], self.vref, N, dt, self.progress_at(s, gait))
+        # WBC inputs (scripts/Controller.py:275-303 shapes)
+        q = np.zeros((B, 19))
+        q[:, 2] = H_REF
+        q[:, 6] = 1.0
+        q[:, 7:] = Q_NOMINAL + self.noise_q[i]
+        dq = np.zeros((B, 18))
+        dq[:, :6] = self.vref
+        dq[:, 6:] = self.noise_dq[i]
+        contacts = gait[:, 0, :].copy()
+        feet = leg_fk(q[:, 7:])  # (B,4,3)
+        swing = (contacts == 0)[:, None, :]  # (B,1,4)
+        ng = self.noise_goal[i]
+        pgoals = np.transpose(feet, (0, 2, 1)) + 0.01 * ng[:, 0].transpose(0, 2, 1)
+        vgoals = np.where(swing, 0.1 * ng[:, 1].transpose(0, 2, 1), 0.0)
+        agoals = np.where(swing, 1.0 * ng[:, 2].transpose(0, 2, 1), 0.0)
+        return dict(xref=xref, fsteps=fsteps, gait=gait, q=q, dq=dq, contacts=contacts, pgoals=pgoals,
+                    vgoals=vgoals, agoals=agoals, x0=x0)

@@ -1,0 +1,171 @@
+"""Checks of the oracle's MPC restatement (oracle/mpc_oracle.c <- /root/reference/src/MPC.cpp).
+
+Pins available: the analytic properties asserted by the reference's stale
+scripts/test_mpc.py:54-85,136-160; the structural invariants of the QP; an independent dense
+assembly of the QP from the documented equations (scripts/Documentation/Equations_MPC_22_02_2020.tex:348-616);
+the optimality conditions of the solved QP.  No numeric vectors exist in the reference.
+"""
+import numpy as np
+import pytest
+
+DT = 0.02
+MASS = np.float64(np.float32(2.50000279))
+MU = np.float64(np.float32(0.9))
+GI = np.array([[3.09249e-2, -8.00101e-7, 1.865287e-5], [-8.00101e-7, 5.106100e-2, 1.245813e-4],
+               [1.865287e-5, 1.245813e-4, 6.939757e-2]])
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def dense_qp(xref, fsteps, N, first_call=False):
+    """Independent dense assembly of (A, l, u, Pdiag) per SURVEY.md Appendix A.1."""
+    n, m = 24 * N, 44 * N
+    A = np.zeros((m, n))
+    Ad = np.eye(12)
+    Ad[:6, 6:] = DT * np.eye(6)
+    gait = (fsteps[:, 0::3] != 0).astype(float)
+    u = np.zeros(m)
+    l = np.zeros(m)
+    for k in range(N):
+        A[12 * k:12 * k + 12, 12 * k:12 * k + 12] = -np.eye(12)
+        if k > 0:
+            A[12 * k:12 * k + 12, 12 * (k - 1):12 * k] = Ad
+        B = np.zeros((12, 12))
+        for i in range(4):
+            B[6:9, 3 * i:3 * i + 3] = DT / MASS * np.eye(3)
+        c, s = np.cos(xref[5, k]), np.sin(xref[5, k])
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+        Iinv = np.linalg.inv(R.T @ GI @ R)
+        for i in range(4):
+            if first_call:
+                foot = np.array([[0.19, 0.19, -0.19, -0.19], [0.15005, -0.15005, 0.15005, -0.15005], [0, 0, 0, 0]])[:, i]
+                lever = foot - xref[0:3, k]
+            else:
+                lever = fsteps[k, 3 * i:3 * i + 3] - (xref[0:3, k] + np.array([0, 0, -0.03]))
+            B[9:12, 3 * i:3 * i + 3] = DT * (Iinv @ skew(lever))
+        A[12 * k:12 * k + 12, 12 * (N + k):12 * (N + k) + 12] = B
+        for i in range(4):
+            for cc in range(3):
+                A[12 * N + 12 * k + 3 * i + cc, 12 * (N + k) + 3 * i + cc] = 1.0 - gait[k, i]
+            r0 = 24 * N + 20 * k + 5 * i
+            c0 = 12 * (N + k) + 3 * i
+            A[r0 + 0, c0 + 0], A[r0 + 0, c0 + 2] = 1.0, -MU
+            A[r0 + 1, c0 + 0], A[r0 + 1, c0 + 2] = -1.0, -MU
+            A[r0 + 2, c0 + 1], A[r0 + 2, c0 + 2] = 1.0, -MU
+            A[r0 + 3, c0 + 1], A[r0 + 3, c0 + 2] = -1.0, -MU
+            A[r0 + 4, c0 + 2] = -1.0
+            l[r0:r0 + 4] = -np.inf
+            l[r0 + 4] = -25.0
+        rhs = np.zeros(12)
+        rhs[8] = np.float64(np.float32(9.81)) * DT
+        rhs += xref[:, k + 1] - Ad @ xref[:, k]
+        u[12 * k:12 * k + 12] = rhs
+        l[12 * k:12 * k + 12] = rhs
+    w = np.array([2.0, 2.0, 20.0, 0.25, 0.25, 10.0] + [np.float32(0.2)] * 3 + [0.0, 0.0, np.float32(0.3)], dtype=np.float64)
+    Pd = np.concatenate([np.tile(w, N), np.full(12 * N, np.float64(np.float32(5e-5)))])
+    return A, l, u, Pd
+
+
+def csc_to_dense(p, i, x, m, n):
+    A = np.zeros((m, n))
+    for j in range(n):
+        A[i[p[j]:p[j + 1]], j] = x[p[j]:p[j + 1]]
+    return A
+
+
+@pytest.mark.parametrize("N", [16, 32])
+def test_qp_assembly_matches_independent_dense_build(oracle_mod, synth_mod, N):
+    sb = synth_mod.SyntheticBatch(2, N, gaits=("trot", "walk"), seed0=99)
+    mpc = [oracle_mod.MPC(DT, N, DT * N, 40 if N > 20 else 20) for _ in range(2)]
+    sb.N_gait = mpc[0].N_gait
+    sb = synth_mod.SyntheticBatch(2, N, N_gait=mpc[0].N_gait, gaits=("trot", "walk"), seed0=99)
+    for s in range(3):
+        d = sb.step(s)
+        for b in range(2):
+            assert mpc[b].run(s, d["xref"][b], d["fsteps"][b]) == 0
+            (p, i, x), (pp, pi, px), lo, up = mpc[b].qp()
+            assert p[-1] == 126 * N - 18  # nnz invariant [SURVEY §8(c)(2)]
+            A = csc_to_dense(p, i, x, 44 * N, 24 * N)
+            A_ref, l_ref, u_ref, Pd = dense_qp(d["xref"][b], d["fsteps"][b], N, first_call=(s == 0))
+            assert np.allclose(A, A_ref, rtol=1e-12, atol=1e-15), (s, b)
+            assert np.allclose(up, u_ref, rtol=1e-12, atol=1e-14)
+            assert np.array_equal(np.isinf(lo), np.isinf(l_ref))
+            fin = np.isfinite(l_ref)
+            assert np.allclose(lo[fin], l_ref[fin], rtol=1e-12, atol=1e-14)
+            assert np.array_equal(px, Pd) and np.array_equal(pi, np.arange(24 * N))
+            # column counts: state columns 2/3 (last block 1), force columns 7,7,10
+            cnt = np.diff(p)
+            assert list(cnt[:12]) == [2] * 6 + [3] * 6 and list(cnt[12 * (N - 1):12 * N]) == [1] * 12
+            assert list(cnt[12 * N:12 * N + 3]) == [7, 7, 10]
+            # gait / S getters (src/MPC.cpp:770-780)
+            g = mpc[b].get_gait()
+            assert np.array_equal(g[:N], (d["fsteps"][b][:N, 0::3] != 0).astype(float))
+            assert np.array_equal(mpc[b].get_Sgait().reshape(N, 4, 3)[:, :, 0], 1.0 - g[:N])
+
+
+def test_fourstance_immobile_properties(oracle_mod):
+    """scripts/test_mpc.py:54-85: equal foot forces, state close to reference; sum f_z = m g."""
+    N = 16
+    m = oracle_mod.MPC(DT, N, 0.32, 20)
+    xref = np.zeros((12, N + 1))
+    xref[2, :] = 0.24474949993103629
+    fsteps = np.zeros((20, 12))
+    fsteps[:N, :] = [0.195, 0.147, 0., 0.195, -0.147, 0., -0.195, 0.147, 0., -0.195, -0.147, 0.]
+    for i in range(100):
+        m.run(i, xref, fsteps)
+        r = m.get_latest_result()
+        xref[:, 0] = r[:12, 0]
+    assert r.shape == (24, N)
+    assert np.allclose(r[12:, 0], np.tile(r[12:15, 0], 4), atol=1e-8)
+    assert np.allclose(r[:12, 0], xref[:, 1], atol=1e-3)
+    assert abs(r[14::3, 0].sum() - 9.81 * 2.50000279) < 1e-3  # the commented analytic value, test_mpc.py:85
+    assert m.status == 1
+
+
+def test_trot_solution_satisfies_optimality_conditions(oracle_mod, synth_mod):
+    N = 16
+    sb = synth_mod.SyntheticBatch(1, N, seed0=5)
+    m = oracle_mod.MPC(DT, N, 0.32, 20)
+    x0 = None
+    for s in range(6):
+        d = sb.step(s, x0)
+        m.run(s, d["xref"][0], d["fsteps"][0])
+        r = m.get_latest_result()
+        x0 = r[:12, 0][None]
+        assert m.status == 1 and m.iter % 25 == 0
+        (p, i, x), (_, _, px), lo, up = m.qp()
+        A = csc_to_dense(p, i, x, 44 * N, 24 * N)
+        sol = m.solution()
+        Ax = A @ sol
+        tol = 1e-6 * (1 + np.abs(Ax).max())
+        assert (Ax <= up + 5 * tol).all() and (Ax >= lo - 5 * tol).all()
+        # swing feet carry no force, stance feet respect the friction pyramid
+        f = r[12:, :].T.reshape(N, 4, 3)
+        gait = d["gait"][0, :N]
+        assert np.abs(f[gait == 0]).max() < 1e-4
+        fs = f[gait == 1]
+        assert (fs[:, 2] >= -1e-4).all() and (fs[:, 2] <= 25 + 1e-4).all()
+        assert (np.abs(fs[:, 0]) <= MU * fs[:, 2] + 1e-4).all() and (np.abs(fs[:, 1]) <= MU * fs[:, 2] + 1e-4).all()
+        # predicted states follow the dynamics rows exactly enough
+        # dynamics rows hold to OSQP's primal tolerance eps_abs + eps_rel*max(|Ax|,|z|) (src/MPC.cpp:529-530)
+        assert np.abs((Ax - up)[:12 * N]).max() <= 1.01e-6 * (1 + np.abs(Ax).max())
+
+
+def test_first_call_uses_default_footholds_then_fsteps(oracle_mod, synth_mod):
+    """src/MPC.cpp:223 vs :438 — B at num_iter==0 ignores fsteps and offset_CoM."""
+    N = 16
+    sb = synth_mod.SyntheticBatch(1, N, seed0=11)
+    d = sb.step(0)
+    m1, m2 = oracle_mod.MPC(DT, N, 0.32, 20), oracle_mod.MPC(DT, N, 0.32, 20)
+    f2 = d["fsteps"][0].copy()
+    f2[:, 0::3] = np.where(f2[:, 0::3] != 0, f2[:, 0::3] + 0.03, 0.0)  # same gait, other footholds
+    m1.run(0, d["xref"][0], d["fsteps"][0])
+    m2.run(0, d["xref"][0], f2)
+    assert np.array_equal(m1.get_latest_result(), m2.get_latest_result())
+    m1.run(1, d["xref"][0], d["fsteps"][0])
+    m2.run(1, d["xref"][0], f2)
+    assert not np.allclose(m1.get_latest_result(), m2.get_latest_result())
+    # an un-setup object refuses num_iter != 0 (the reference would dereference a null workspace)
+    assert oracle_mod.MPC(DT, N, 0.32, 20).run(3, d["xref"][0], d["fsteps"][0]) != 0

@@ -1,0 +1,151 @@
+"""Physical-consistency checks of the oracle's rigid-body restatement (oracle/rbd_oracle.c).
+
+The reference holds no vectors for these Pinocchio calls (scripts/QP_WBC.py:89-116,
+scripts/solo12InvKin.py:47-59), so the restatement is pinned by identities every correct
+implementation satisfies, plus the model constants the reference embeds.
+"""
+import numpy as np
+import pytest
+
+Q_NOM = np.array([0.0, 0.7, -1.4, 0.0, 0.7, -1.4, 0.0, -0.7, 1.4, 0.0, -0.7, 1.4])
+MASS = 2.50000279  # src/MPC.cpp:17, scripts/test_mpc.py:31
+
+
+def rand_q19(rng):
+    q = np.zeros(19)
+    q[:3] = rng.uniform(-0.3, 0.3, 3)
+    quat = rng.normal(size=4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] = Q_NOM + rng.uniform(-0.4, 0.4, 12)
+    return q
+
+
+def quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_model_constants_match_reference(oracle_mod, synth_mod):
+    # standing configuration: feet under the shoulders at (±0.1946, ±0.14695), height 0.32*cos(0.7)
+    posf, *_ = oracle_mod.fixed_feet(Q_NOM, np.zeros(12))
+    assert np.allclose(np.abs(posf[:, 0]), 0.1946, atol=1e-12)  # scripts/Controller.py:132
+    assert np.allclose(np.abs(posf[:, 1]), 0.14695, atol=1e-12)  # scripts/Controller.py:133
+    assert np.allclose(posf[:, 2], -0.32 * np.cos(0.7), atol=1e-12)  # scripts/test_mpc.py:39
+    assert np.allclose(posf, synth_mod.leg_fk(Q_NOM)[0], atol=1e-14)
+    # total mass from the mass matrix
+    q = np.zeros(19)
+    q[6] = 1.0
+    M = oracle_mod.crba(q)
+    assert np.allclose(M[:3, :3], MASS * np.eye(3), atol=1e-12)
+
+
+def test_gravity_compensation_and_symmetry(oracle_mod):
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        q = rand_q19(rng)
+        tau = oracle_mod.rnea(q, np.zeros(18), np.zeros(18))
+        R = quat_R(q[3:7])
+        # base force at rest = weight, expressed in the base frame
+        assert np.allclose(R @ tau[:3], [0, 0, MASS * 9.81], atol=1e-10)
+        M = oracle_mod.crba(q)
+        assert np.allclose(M, M.T, atol=1e-12)
+        assert np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
+        assert np.allclose(oracle_mod.crba_base_block(q), M[:6, :6], atol=1e-12)
+
+
+def test_rnea_is_M_a_plus_bias(oracle_mod):
+    rng = np.random.default_rng(2)
+    q = rand_q19(rng)
+    v = rng.uniform(-1, 1, 18)
+    a = rng.uniform(-3, 3, 18)
+    M = oracle_mod.crba(q)
+    b = oracle_mod.rnea(q, v, np.zeros(18))
+    assert np.allclose(oracle_mod.rnea(q, v, a), M @ a + b, atol=1e-10)
+
+
+def _integrate(q, v, h):
+    """q (+) v*h on SE(3) x R^12 with v in the base frame (first-order is enough for FD checks)."""
+    qn = q.copy()
+    R = quat_R(q[3:7])
+    qn[:3] = q[:3] + R @ v[:3] * h
+    w = v[3:6] * h
+    dq = np.array([0.5 * w[0], 0.5 * w[1], 0.5 * w[2], 1.0])
+    x1, y1, z1, w1 = q[3:7]
+    x2, y2, z2, w2 = dq
+    qq = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                   w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+    qn[3:7] = qq / np.linalg.norm(qq)
+    qn[7:] = q[7:] + v[6:] * h
+    return qn
+
+
+def _feet_world(oracle_mod, q):
+    posf, *_ = oracle_mod.fixed_feet(q[7:], np.zeros(12))
+    R = quat_R(q[3:7])
+    return (R @ posf.T).T + q[:3]
+
+
+def test_free_flyer_jacobian_vs_finite_differences(oracle_mod):
+    rng = np.random.default_rng(3)
+    q = rand_q19(rng)
+    J = oracle_mod.feet_jacobians(q)
+    h = 1e-6
+    for k in range(18):
+        e = np.zeros(18)
+        e[k] = 1.0
+        d = (_feet_world(oracle_mod, _integrate(q, e, h)) - _feet_world(oracle_mod, _integrate(q, e, -h))) / (2 * h)
+        assert np.allclose(J[:, k], d.reshape(-1), atol=1e-6), k
+
+
+def test_fixed_base_velocity_and_acceleration(oracle_mod):
+    rng = np.random.default_rng(4)
+    q = Q_NOM + rng.uniform(-0.4, 0.4, 12)
+    dq = rng.uniform(-2, 2, 12)
+    posf, vf, wf, af, Jf = oracle_mod.fixed_feet(q, dq)
+    assert np.allclose(vf.reshape(-1), Jf @ dq, atol=1e-12)
+    # off-leg blocks of the Jacobian are zero (src/InvKin.cpp:56 inverts only the diagonal blocks)
+    for i in range(4):
+        for j in range(4):
+            if i != j:
+                assert np.all(Jf[3 * i:3 * i + 3, 3 * j:3 * j + 3] == 0)
+    h = 1e-6
+    p_plus, *_ = oracle_mod.fixed_feet(q + h * dq, dq)
+    p_minus, *_ = oracle_mod.fixed_feet(q - h * dq, dq)
+    assert np.allclose((p_plus - p_minus) / (2 * h), vf, atol=1e-7)
+    # classical acceleration (zero joint acceleration) = spatial + w x v  (src/InvKin.cpp:48)
+    _, v_plus, *_ = oracle_mod.fixed_feet(q + h * dq, dq)
+    _, v_minus, *_ = oracle_mod.fixed_feet(q - h * dq, dq)
+    classical = (v_plus - v_minus) / (2 * h)
+    assert np.allclose(af + np.cross(wf, vf), classical, atol=1e-6)
+    # angular velocity of the lower leg: sum of joint axis rates in the base frame
+    for leg in range(4):
+        q0 = q[3 * leg]
+        axis_y = np.array([0.0, np.cos(q0), np.sin(q0)])
+        w = np.array([1.0, 0, 0]) * dq[3 * leg] + axis_y * (dq[3 * leg + 1] + dq[3 * leg + 2])
+        assert np.allclose(wf[leg], w, atol=1e-12)
+
+
+def test_invkin_matches_formulas(oracle_mod):
+    """src/InvKin.cpp:36-62 against a direct numpy evaluation."""
+    rng = np.random.default_rng(5)
+    q = Q_NOM + rng.uniform(-0.2, 0.2, 12)
+    dq = rng.uniform(-1, 1, 12)
+    posf, vf, wf, af, Jf = oracle_mod.fixed_feet(q, dq)
+    contacts = np.array([1.0, 0.0, 0.0, 1.0])
+    goals = posf.T + rng.uniform(-0.01, 0.01, (3, 4))
+    vgoals = rng.uniform(-0.1, 0.1, (3, 4))
+    agoals = rng.uniform(-1, 1, (3, 4))
+    ik = oracle_mod.InvKin(0.002)
+    ddq = ik.refreshAndCompute(contacts, goals, vgoals, agoals, posf, vf, wf, af, Jf)
+    for i in range(4):
+        e = goals[:, i] - posf[i]
+        a = 100.0 * e - 20.0 * (vf[i] - vgoals[:, i]) + agoals[:, i]
+        if contacts[i]:
+            a = a * 0.0
+        a = a - (af[i] + np.cross(wf[i], vf[i]))
+        iJ = np.linalg.inv(Jf[3 * i:3 * i + 3, 3 * i:3 * i + 3])
+        assert np.allclose(ddq[3 * i:3 * i + 3], iJ @ a, rtol=1e-10, atol=1e-10)
+        assert np.allclose(ik.get_dq_cmd()[3 * i:3 * i + 3], iJ @ vgoals[:, i], rtol=1e-10, atol=1e-12)
+        assert np.allclose(ik.get_q_step()[3 * i:3 * i + 3], iJ @ e, rtol=1e-10, atol=1e-12)
