@@ -1,0 +1,142 @@
+/*
+ * include/qrw_hip.h — C ABI of libqrw_hip.so, the MI355X (gfx950) implementation of the
+ * quadruped-reactive-walking control-loop hot path, batched over B independent Solo12
+ * instances.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Each entry point names the reference interface it replaces (paths under
+ * /root/reference).  In the reference these are Boost.Python/eigenpy bound C++ methods
+ * (python/gepadd.cpp) called from scripts/MPC_Wrapper.py and scripts/QP_WBC.py; here the
+ * same calls arrive through ctypes (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions
+ *   - all arrays are C-order (row-major) doubles with the reference's own shapes and a
+ *     leading batch dimension B; `d_` pointers are device (HBM) pointers, `h_` host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); device-pointer
+ *     entry points only enqueue work and never synchronise or allocate;
+ *   - every function returns 0 on success, <0 on error (qrw_last_error() has the text);
+ *     like the reference (src/MPC.cpp:558,648; src/QPWBC.cpp:270,389) a solver that stops
+ *     at max-iter or detects infeasibility is NOT an error: its status is reported per
+ *     instance through qrw_*_get_stats and the (possibly NaN) result is passed through;
+ *   - a handle owns the per-instance persistent solver state (warm start, rho, stale
+ *     B/S entries — SURVEY.md §0.4) of ONE GPU's shard; single caller, not thread-safe.
+ */
+#ifndef QRW_HIP_H_
+#define QRW_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qrw_handle_s *qrw_handle;
+
+typedef struct {
+  int32_t batch;   /* B: instances owned by this handle                                  */
+  int32_t n_steps; /* N: MPC horizon steps, MPC::MPC n_steps_in (src/MPC.cpp:3); 1..32   */
+  int32_t N_gait;  /* rows of fsteps / gait matrices, MPC::MPC N_gait; >= n_steps        */
+  int32_t device;  /* HIP device ordinal                                                  */
+  double dt_mpc;   /* MPC::MPC dt_in (src/config_solo12.yaml:11 -> 0.02)                  */
+  double T_gait;   /* MPC::MPC T_gait_in (unused by the maths, kept for the call surface) */
+  double dt_wbc;   /* wbc_controller dt / InvKin dt (scripts/QP_WBC.py:18 -> 0.002)       */
+} qrw_config;
+
+/* solver status values (OSQP constants, as ignored by src/MPC.cpp:558) */
+#define QRW_STATUS_SOLVED 1
+#define QRW_STATUS_SOLVED_INACCURATE 2
+#define QRW_STATUS_MAX_ITER_REACHED (-2)
+#define QRW_STATUS_PRIMAL_INFEASIBLE (-3)
+#define QRW_STATUS_DUAL_INFEASIBLE (-4)
+#define QRW_STATUS_NON_CVX (-7)
+#define QRW_STATUS_UNSOLVED (-10)
+#define QRW_STATUS_NOT_SETUP (-100) /* run with num_iter != 0 before any num_iter == 0 call */
+
+/* Replaces the constructors MPC::MPC (src/MPC.cpp:3-32; binding python/gepadd.cpp:22-24),
+ * QPWBC::QPWBC (src/QPWBC.cpp:4-30; python/gepadd.cpp:217) and InvKin::InvKin
+ * (src/InvKin.cpp:3-10; python/gepadd.cpp:186) for a batch of B instances. */
+int qrw_create(const qrw_config *cfg, qrw_handle *out);
+int qrw_destroy(qrw_handle h);
+const char *qrw_last_error(void);
+
+/* Replaces MPC::run(num_iter, xref_in, fsteps_in) + MPC::get_latest_result()
+ * (src/MPC.cpp:626-649,604; python/gepadd.cpp:27-29), i.e. what
+ * MPC_Wrapper.run_MPC_synchronous does (scripts/MPC_Wrapper.py:142,148), per instance.
+ *   d_xref     [B][12][N+1]   column 0 = current state
+ *   d_fsteps   [B][N_gait][12] row i = horizon step i, zero = swing / beyond horizon
+ *   d_num_iter [B] int32 or NULL; if NULL num_iter_scalar applies to every instance.
+ *              num_iter == 0 (re)creates the QP and cold-starts the solver (MPC.cpp:636-637)
+ *   d_out      [B][24][N]     x_f_applied: rows 0-11 predicted states, 12-23 forces */
+int qrw_mpc_solve(qrw_handle h, const double *d_xref, const double *d_fsteps, const int32_t *d_num_iter,
+                  int32_t num_iter_scalar, double *d_out, void *stream);
+/* same with host buffers (H2D, solve, D2H, synchronised) — used by the single-robot drop-in */
+int qrw_mpc_solve_host(qrw_handle h, const double *h_xref, const double *h_fsteps, const int32_t *h_num_iter,
+                       int32_t num_iter_scalar, double *h_out);
+
+/* MPC::get_gait / MPC::get_Sgait (src/MPC.cpp:770-780; python/gepadd.cpp:30-31) of instance b:
+ * h_gait [N_gait][4], h_Sgait [12 N] */
+int qrw_mpc_get_gait(qrw_handle h, int32_t b, double *h_gait, double *h_Sgait);
+
+/* Per-instance solver statistics of the last qrw_mpc_solve (host arrays of B, any may be NULL).
+ * The reference never inspects them (OSQP status ignored); exposed so the silent
+ * pass-through can be observed (SURVEY.md §8(b) error convention). */
+int qrw_mpc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double *h_rho, double *h_pri_res,
+                      double *h_dua_res);
+
+/* Diagnostic: OSQP-ordered copies of instance b's persisted scaled iterates x[24N], z[44N],
+ * y[44N] and of the last solve's scaling D[24N], E[44N], c (any may be NULL). Tests only. */
+int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double *h_y, double *h_D, double *h_E,
+                      double *h_c);
+
+/* Replaces wbc_controller.compute (scripts/QP_WBC.py:52-131) with everything it calls:
+ * Solo12InvKin.refreshAndCompute (scripts/solo12InvKin.py:44-69), InvKin::refreshAndCompute
+ * (src/InvKin.cpp:23-73), the Pinocchio crba/Jacobian/rnea calls (QP_WBC.py:89-116) and
+ * QPWBC::run + getters (src/QPWBC.cpp:310-390,302-308; python/gepadd.cpp:219-223).
+ *   in : d_q [B][19], d_dq [B][18], d_f_cmd [B][12], d_contacts [B][4],
+ *        d_pgoals / d_vgoals / d_agoals [B][3][4]
+ *   out: d_tau_ff [B][12], d_qdes [B][19], d_vdes [B][18], d_f_with_delta [B][12],
+ *        d_ddq_res [B][6] (QPWBC::get_ddq_res), d_feet [B][3][3][4] = feet_pos, feet_err,
+ *        feet_vel (QP_WBC.py:73-80); any output may be NULL */
+int qrw_wbc_compute(qrw_handle h, const double *d_q, const double *d_dq, const double *d_f_cmd,
+                    const double *d_contacts, const double *d_pgoals, const double *d_vgoals, const double *d_agoals,
+                    double *d_tau_ff, double *d_qdes, double *d_vdes, double *d_f_with_delta, double *d_ddq_res,
+                    double *d_feet, void *stream);
+int qrw_wbc_compute_host(qrw_handle h, const double *h_q, const double *h_dq, const double *h_f_cmd,
+                         const double *h_contacts, const double *h_pgoals, const double *h_vgoals,
+                         const double *h_agoals, double *h_tau_ff, double *h_qdes, double *h_vdes,
+                         double *h_f_with_delta, double *h_ddq_res, double *h_feet);
+int qrw_wbc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double *h_rho, double *h_k_since_contact);
+
+/* Stand-alone pieces of the WBC step with the reference's own signatures, for callers that
+ * use the bound classes directly (scripts/solo12InvKin.py:62-67, scripts/QP_WBC.py:107-111):
+ * InvKin::refreshAndCompute (+ get_q_step, get_dq_cmd): host arrays, batch of B.
+ *   h_contacts [B][4], h_goals/vgoals/agoals [B][3][4], h_posf/vf/wf/af [B][4][3], h_Jf [B][12][12]
+ *   -> h_ddq, h_dq_cmd, h_q_step [B][12] */
+int qrw_invkin_host(qrw_handle h, const double *h_contacts, const double *h_goals, const double *h_vgoals,
+                    const double *h_agoals, const double *h_posf, const double *h_vf, const double *h_wf,
+                    const double *h_af, const double *h_Jf, double *h_ddq, double *h_dq_cmd, double *h_q_step);
+/* QPWBC::run(M, Jc, f_cmd, RNEA, k_contacts) + get_f_res / get_ddq_res / get_H:
+ *   h_M [B][18][18] (only the diagonal of its top-left 6x6 is read: the caller masks it,
+ *   scripts/QP_WBC.py:93), h_Jc [B][12][18], h_f_cmd [B][12], h_RNEA [B][6]
+ *   -> h_f_res [B][12], h_ddq_res [B][6], h_H [B][12][12] (may be NULL) */
+int qrw_qpwbc_host(qrw_handle h, const double *h_M, const double *h_Jc, const double *h_f_cmd, const double *h_RNEA,
+                   double *h_f_res, double *h_ddq_res, double *h_H);
+
+/* Rigid-body slice used by Solo12InvKin (scripts/solo12InvKin.py:47-59): fixed-base feet
+ * kinematics. h_q12/h_dq12 [B][12] -> h_posf/vf/wf/af [B][4][3], h_Jf [B][12][12] */
+int qrw_fixed_feet_host(qrw_handle h, const double *h_q12, const double *h_dq12, double *h_posf, double *h_vf,
+                        double *h_wf, double *h_af, double *h_Jf);
+
+/* Diagonal of the neutral-configuration CRBA base block (scripts/QP_WBC.py:89-93), constant. */
+int qrw_get_base_inertia_diag(qrw_handle h, double *h_Y6);
+
+/* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 has the operand layout the MPC
+ * chain sweeps assume. 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
+int qrw_selftest_mfma(double *max_err);
+
+/* workspace sizes, for callers that budget HBM */
+int64_t qrw_state_bytes(qrw_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QRW_HIP_H_ */

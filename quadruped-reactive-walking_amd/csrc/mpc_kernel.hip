@@ -1,0 +1,985 @@
+// MPC QP build + OSQP-style ADMM solve for a batch of Solo12 instances — gfx950 (MI355X).
+//
+// Replaces, per instance, MPC::run of the reference (/root/reference/src/MPC.cpp:626-649):
+//   construct_gait :686-701, construct_S :665-681, create_ML/update_ML :74-256/:418-464 (only
+//   the 36 B coefficients + 12 S flags per step vary; the sparsity is compile-time here),
+//   create_NK/update_NK :261-312/:469-496, create_weight_matrices :317-391, call_solver
+//   :501-564 (OSQP 0.6.x: scale_data, osqp_update_A/bounds, osqp_solve — restated from the
+//   published algorithm, see oracle/osqp_restate.h) and retrieve_result :569-599.
+//
+// Mapping: ONE WAVEFRONT PER ROBOT INSTANCE, lane = 4*k + j with k = horizon step, j = foot.
+// Lane (k,j) owns state entries X_k[3j..3j+2], force entries f_k[3j..3j+2], dynamics rows
+// (k,3j..3j+2), force-enable rows (k,3j..3j+2) and the 5 friction-cone rows of foot j at step k:
+// 6 of the 24N variables and 11 of the 44N constraints per lane — all ADMM vectors live in
+// registers.  The KKT solve (P + sigma I + A' R A) x = r is done by block elimination:
+//   1. forces f_k are eliminated per step inside each quad (12x12 inverse held as 3 rows per lane),
+//   2. the remaining block-tridiagonal system in the states (12x12 blocks, N steps) is solved by a
+//      block LDL' recursion whose two sequential sweeps run on the FP64 matrix cores
+//      (v_mfma_f64_16x16x4: y = c - N v with the 12-vector replicated across the 16 columns, so
+//      the D-layout of one step is exactly the B-operand of the next: no cross-lane traffic),
+//   3. forces are back-substituted inside each quad.
+// LDS holds the N-1 chain matrices (column-major 12x12) and one 12N exchange vector.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "qrw_device.h"
+#include "qrw_kernels.h"
+
+namespace qrw {
+
+namespace {
+
+constexpr int kMatSz = 144;
+constexpr int kWSz = 36;
+
+// LDS carve (doubles). Chain matrices -N_k (k = 1..N-1), exchange vector, factor scratch.
+struct MpcLds {
+  double sN[(kMpcMaxN - 1) * kMatSz];
+  double sX[kMpcMaxN * 12];
+  double sW[kMpcMaxN * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
+  double sOm[kMpcMaxN * 12];    // omega_D per step (factor phase)
+  double sDg[kMpcMaxN * 12];    // c*w + sigma/Dx^2 per step (factor phase)
+  double sA[kMatSz];            // Delta_{k-1}^-1
+  double sB[kMatSz];            // Delta_k (inverted in place)
+};
+
+__device__ __forceinline__ void wg_sync() { __syncthreads(); }
+
+// ---- friction-cone block helpers (rows: fx-mu fz, -fx-mu fz, fy-mu fz, -fy-mu fz, -fz; MPC.cpp:130-146)
+__device__ __forceinline__ void cone_apply(const double f[3], double mu, double out[5]) {
+  out[0] = f[0] - mu * f[2];
+  out[1] = -f[0] - mu * f[2];
+  out[2] = f[1] - mu * f[2];
+  out[3] = -f[1] - mu * f[2];
+  out[4] = -f[2];
+}
+__device__ __forceinline__ void cone_apply_t(const double w[5], double mu, double out[3]) {
+  out[0] = w[0] - w[1];
+  out[1] = w[2] - w[3];
+  out[2] = -mu * (w[0] + w[1] + w[2] + w[3]) - w[4];
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
+  __shared__ MpcLds L;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int k = lane >> 2, j = lane & 3;
+  const int N = a.N;
+  const bool act = k < N;
+  const bool has_next = act && (k + 1 < N);
+  const bool has_prev = act && (k > 0);
+  const int mrow = lane & 15, mq = lane >> 4;  // MFMA operand coordinates
+
+  // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
+  const double dt = a.dt;
+  const double mass = (double)2.50000279f;
+  const double mu = (double)0.9f;
+  const double dtm = dt / mass;
+  const double g8 = (double)(9.81f) * dt;
+  const double wF = (double)5e-5f;
+  const double sigma = 1e-6, alpha = 1.6;
+  const double eps_abs = 1e-6, eps_rel = 1e-6;
+  const double w_all[12] = {2.0, 2.0, 20.0, 0.25, 0.25, 10.0, (double)0.2f, (double)0.2f,
+                            (double)0.2f, 0.0, 0.0, (double)0.3f};
+  double wX[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) wX[t] = (j == 0) ? w_all[t] : (j == 1) ? w_all[3 + t] : (j == 2) ? w_all[6 + t] : w_all[9 + t];
+
+  const double* xr = a.xref + (size_t)b * 12 * (N + 1);
+  const double* fs = a.fsteps + (size_t)b * a.N_gait * 12;
+  double* st = a.st + (size_t)b * kMpcStItems * 64;
+  const int num_iter = a.num_iter ? a.num_iter[b] : a.num_iter_scalar;
+  const bool first = (num_iter == 0);
+#define ST(item) st[(item)*64 + lane]
+
+  if (!first && !a.flags[b]) {  // reference would dereference an un-setup OSQP workspace
+    if (lane == 0) {
+      a.status[b] = kStatusNotSetup;
+      a.iters[b] = 0;
+    }
+    if (act) {
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        a.out[(size_t)b * 24 * N + (3 * j + t) * N + k] = nan("");
+        a.out[(size_t)b * 24 * N + (12 + 3 * j + t) * N + k] = nan("");
+      }
+    }
+    return;
+  }
+
+  // =========================== A. assemble (MPC.cpp:626-640) ===========================
+  // construct_gait (:686-701): rows until the first all-zero row of fsteps
+  double f3[3] = {0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) f3[t] = fs[k * 12 + 3 * j + t];
+  }
+  const bool mynz = act && (f3[0] != 0.0 || f3[1] != 0.0 || f3[2] != 0.0);
+  const unsigned long long bal = __ballot(mynz);
+  int len = N;
+  for (int kk = N - 1; kk >= 0; kk--)
+    if (((bal >> (4 * kk)) & 0xFull) == 0) len = kk;
+  const bool in_gait = k < len;
+
+  double Bang[3][3];  // B[9+r][3j+t] of step k (MPC.cpp:440)
+  double sfl[3];      // S_gait entries of (k, foot j) (MPC.cpp:665-681)
+  double rho;
+  double xX[3], xF[3], zD[3], zC[5], yD[3], yS[3], yC[5];
+  if (first) {
+    rho = 0.1;
+#pragma unroll
+    for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = sfl[t] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) zC[c] = yC[c] = 0.0;
+  } else {
+    rho = ST(kStRho);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      xX[t] = ST(kStXX + t); xF[t] = ST(kStXF + t); zD[t] = ST(kStZD + t);
+      yD[t] = ST(kStYD + t); yS[t] = ST(kStYS + t); sfl[t] = ST(kStS + t);
+#pragma unroll
+      for (int r = 0; r < 3; r++) Bang[r][t] = ST(kStB + r * 3 + t);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) { zC[c] = ST(kStZC + c); yC[c] = ST(kStYC + c); }
+  }
+
+  // B block: dt * I_inv * skew(lever) (MPC.cpp:213-232 first call, :425-447 afterwards)
+  if (act && (first || in_gait)) {
+    const double yaw = xr[5 * (N + 1) + k];
+    const double c = cos(yaw), s = sin(yaw);
+    const double gI[9] = {3.09249e-2, -8.00101e-7, 1.865287e-5, -8.00101e-7, 5.106100e-2,
+                          1.245813e-4, 1.865287e-5, 1.245813e-4, 6.939757e-2};
+    const double R[9] = {c, -s, 0.0, s, c, 0.0, 0.0, 0.0, 1.0};
+    double T[9], M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        double acc = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc += R[kk * 3 + i] * gI[kk * 3 + jj];
+        T[i * 3 + jj] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        double acc = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc += T[i * 3 + kk] * R[kk * 3 + jj];
+        M[i * 3 + jj] = acc;
+      }
+    const double c00 = M[4] * M[8] - M[5] * M[7], c10 = M[5] * M[6] - M[3] * M[8], c20 = M[3] * M[7] - M[4] * M[6];
+    const double invdet = 1.0 / (M[0] * c00 + M[1] * c10 + M[2] * c20);
+    double Ii[9];
+    Ii[0] = c00 * invdet; Ii[1] = (M[2] * M[7] - M[1] * M[8]) * invdet; Ii[2] = (M[1] * M[5] - M[2] * M[4]) * invdet;
+    Ii[3] = c10 * invdet; Ii[4] = (M[0] * M[8] - M[2] * M[6]) * invdet; Ii[5] = (M[2] * M[3] - M[0] * M[5]) * invdet;
+    Ii[6] = c20 * invdet; Ii[7] = (M[1] * M[6] - M[0] * M[7]) * invdet; Ii[8] = (M[0] * M[4] - M[1] * M[3]) * invdet;
+    double l[3];
+    if (first) {  // default footholds, NO offset_CoM (MPC.cpp:24,223)
+      const double fx = (j < 2) ? 0.19 : -0.19, fy = (j & 1) ? -0.15005 : 0.15005;
+      l[0] = fx - xr[0 * (N + 1) + k];
+      l[1] = fy - xr[1 * (N + 1) + k];
+      l[2] = 0.0 - xr[2 * (N + 1) + k];
+    } else {  // fsteps row k, offset_CoM = (0,0,-0.03) (MPC.cpp:21,438)
+      l[0] = f3[0] - (xr[0 * (N + 1) + k] + 0.0);
+      l[1] = f3[1] - (xr[1 * (N + 1) + k] + 0.0);
+      l[2] = f3[2] - (xr[2 * (N + 1) + k] + -0.03);
+    }
+    const double S[9] = {0.0, -l[2], l[1], l[2], 0.0, -l[0], -l[1], l[0], 0.0};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double acc = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc += Ii[r * 3 + kk] * S[kk * 3 + t];
+        Bang[r][t] = dt * acc;
+      }
+  } else if (first) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) Bang[r][t] = 0.0;
+  }
+  if (act && in_gait) {
+    const double sv = (f3[0] == 0.0) ? 1.0 : 0.0;  // 1 - gait[k][j]
+#pragma unroll
+    for (int t = 0; t < 3; t++) sfl[t] = sv;
+  }
+  // gait matrix for the getter (MPC.cpp:686-701): rows < len rewritten, row len zeroed
+  {
+    int* gg = a.gait + (size_t)b * a.N_gait * 4;
+    if (first)
+      for (int e = lane; e < a.N_gait * 4; e += 64) gg[e] = 0;
+    __syncthreads();
+    if (act && in_gait) gg[k * 4 + j] = (f3[0] == 0.0) ? 0 : 1;
+    if (act && k == len && len < a.N_gait) gg[k * 4 + j] = 0;
+    if (len == N && N < a.N_gait && lane < 4) gg[N * 4 + lane] = 0;
+  }
+
+  // bounds of the dynamics rows (MPC.cpp:476-486): u = -g - A x0 (first block) + D vec(xref[:,1:])
+  double uD0[3];
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int i = 3 * j + t;
+      const double xk = xr[i * (N + 1) + k];
+      const double xk1 = xr[i * (N + 1) + k + 1];
+      double am = -xk;
+      if (j < 2) am += -dt * xr[(i + 6) * (N + 1) + k];
+      const double gterm = (i == 8) ? g8 : 0.0;
+      uD0[t] = (k == 0) ? ((gterm + am) + xk1) : (gterm + (am + xk1));
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; t++) uD0[t] = 0.0;
+  }
+
+  // =========================== B. Ruiz equilibration (OSQP scale_data) ===========================
+  double Dx[3] = {1, 1, 1}, Df[3] = {1, 1, 1}, Ed[3] = {1, 1, 1}, Es[3] = {1, 1, 1}, Ec[5] = {1, 1, 1, 1, 1};
+  double cs = 1.0;
+  double aB[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int t = 0; t < 3; t++) aB[r][t] = fabs(Bang[r][t]);
+  const double inv_n = 1.0 / (double)(24 * N);
+  for (int pass = 0; pass < 10; pass++) {
+    double nX[3], nF[3], nD[3], nS[3], nC[5];
+    double EdL[3], EdA[3], mDf[3], mBD[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const double En = shfl(Ed[t], lane + 4);
+      const double En6 = shfl(Ed[t], lane + 2);
+      const double Dxp = shfl(Dx[t], lane - 4);
+      const double Dxp6 = shfl(Dx[t], lane - 2);
+      EdL[t] = quad_bcast<2>(Ed[t]);
+      EdA[t] = quad_bcast<3>(Ed[t]);
+      mDf[t] = quad_max(Df[t]);
+      double mb = fmax(fmax(aB[t][0] * Df[0], aB[t][1] * Df[1]), aB[t][2] * Df[2]);
+      mBD[t] = quad_max(mb);
+      // column of X_k[3j+t]
+      double v = fabs(cs * wX[t] * Dx[t] * Dx[t]);
+      v = fmax(v, Ed[t] * Dx[t]);
+      if (has_next) {
+        v = fmax(v, En * Dx[t]);
+        if (j >= 2) v = fmax(v, dt * En6 * Dx[t]);
+      }
+      nX[t] = v;
+      // dynamics row (k, 3j+t)
+      double r_ = Ed[t] * Dx[t];
+      if (has_prev) {
+        r_ = fmax(r_, Ed[t] * Dxp);
+        if (j < 2) r_ = fmax(r_, dt * Ed[t] * Dxp6);
+      }
+      nD[t] = r_;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      if (j == 2) nD[t] = fmax(nD[t], Ed[t] * dtm * mDf[t]);
+      if (j == 3) nD[t] = fmax(nD[t], Ed[t] * mBD[t]);
+      double v = fabs(cs * wF * Df[t] * Df[t]);
+      v = fmax(v, dtm * EdL[t] * Df[t]);
+#pragma unroll
+      for (int r = 0; r < 3; r++) v = fmax(v, aB[r][t] * EdA[r] * Df[t]);
+      v = fmax(v, sfl[t] * Es[t] * Df[t]);
+      nF[t] = v;
+      nS[t] = sfl[t] * Es[t] * Df[t];
+    }
+    nF[0] = fmax(nF[0], fmax(Ec[0], Ec[1]) * Df[0]);
+    nF[1] = fmax(nF[1], fmax(Ec[2], Ec[3]) * Df[1]);
+    nF[2] = fmax(nF[2], fmax(fmax(fmax(mu * Ec[0], mu * Ec[1]), fmax(mu * Ec[2], mu * Ec[3])), Ec[4]) * Df[2]);
+    nC[0] = Ec[0] * fmax(Df[0], mu * Df[2]);
+    nC[1] = Ec[1] * fmax(Df[0], mu * Df[2]);
+    nC[2] = Ec[2] * fmax(Df[1], mu * Df[2]);
+    nC[3] = Ec[3] * fmax(Df[1], mu * Df[2]);
+    nC[4] = Ec[4] * Df[2];
+    double colsum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      Dx[t] *= 1.0 / sqrt(limit_scaling(nX[t]));
+      Df[t] *= 1.0 / sqrt(limit_scaling(nF[t]));
+      Ed[t] *= 1.0 / sqrt(limit_scaling(nD[t]));
+      Es[t] *= 1.0 / sqrt(limit_scaling(nS[t]));
+      colsum += fabs(cs * wX[t] * Dx[t] * Dx[t]) + fabs(cs * wF * Df[t] * Df[t]);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) Ec[c] *= 1.0 / sqrt(limit_scaling(nC[c]));
+    // cost normalisation: c_temp = max(mean ||P cols||inf, ||q||inf -> 1 because q = 0)
+    double ct = wave_sum(act ? colsum : 0.0) * inv_n;
+    ct = fmax(ct, 1.0);
+    ct = limit_scaling(ct);
+    cs *= 1.0 / ct;
+  }
+  const double cinv = 1.0 / cs;
+  double iDx[3], iDf[3], iEd[3], iEs[3], iEc[5];
+  double uD[3], lC4;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    iDx[t] = 1.0 / Dx[t]; iDf[t] = 1.0 / Df[t]; iEd[t] = 1.0 / Ed[t]; iEs[t] = 1.0 / Es[t];
+    uD[t] = Ed[t] * uD0[t];
+  }
+#pragma unroll
+  for (int c = 0; c < 5; c++) iEc[c] = 1.0 / Ec[c];
+  lC4 = Ec[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
+
+  // factor data (per lane: 3 rows of F_k^-1, Delta_k^-1 and Phi_k = F_k^-1 Gbar_k')
+  double Fi[3][12], Di[3][12], Ph[3][6];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+#pragma unroll
+    for (int c = 0; c < 12; c++) Fi[t][c] = Di[t][c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) Ph[t][c] = 0.0;
+  }
+
+  // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
+  bool need_factor = true;
+  int iter = 0, status = kStatusUnsolved, rho_updates = 0;
+  double pri_res = 0.0, dua_res = 0.0;
+  const int max_iter = 4000;
+  rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+
+  for (iter = 1; iter <= max_iter; iter++) {
+    if (need_factor) {
+      need_factor = false;
+      const double rho_eq = kRhoEqOverIneq * rho;
+      double omD[3], omS[3], omC[5];
+#pragma unroll
+      for (int t = 0; t < 3; t++) { omD[t] = rho_eq * Ed[t] * Ed[t]; omS[t] = rho_eq * Es[t] * Es[t]; }
+#pragma unroll
+      for (int c = 0; c < 5; c++) omC[c] = rho * Ec[c] * Ec[c];
+      // ---- force block F_k (rows of foot j), inverted inside the quad by Gauss-Jordan
+      double Ball[3][12];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          Ball[r][0 + t] = quad_bcast<0>(Bang[r][t]);
+          Ball[r][3 + t] = quad_bcast<1>(Bang[r][t]);
+          Ball[r][6 + t] = quad_bcast<2>(Bang[r][t]);
+          Ball[r][9 + t] = quad_bcast<3>(Bang[r][t]);
+        }
+      double omL[3], omA[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) { omL[t] = quad_bcast<2>(omD[t]); omA[t] = quad_bcast<3>(omD[t]); }
+      const double s4 = omC[0] + omC[1] + omC[2] + omC[3];
+      double cone[3][3] = {{omC[0] + omC[1], 0.0, -mu * (omC[0] - omC[1])},
+                           {0.0, omC[2] + omC[3], -mu * (omC[2] - omC[3])},
+                           {-mu * (omC[0] - omC[1]), -mu * (omC[2] - omC[3]), mu * mu * s4 + omC[4]}};
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int cb = 0; cb < 12; cb++) {
+          const int jb = cb / 3, tb = cb % 3;
+          double v = 0.0;
+#pragma unroll
+          for (int r = 0; r < 3; r++) v += omA[r] * Bang[r][t] * Ball[r][cb];
+          if (tb == t) v += dtm * dtm * omL[t];
+          if (jb == j) {
+            v += cone[t][tb];
+            if (tb == t) v += cs * wF + sigma * iDf[t] * iDf[t] + sfl[t] * sfl[t] * omS[t];
+          }
+          Fi[t][cb] = act ? v : ((jb == j && tb == t) ? 1.0 : 0.0);
+        }
+#pragma unroll
+      for (int p = 0; p < 12; p++) {
+        const int jp = p / 3, tp = p % 3;
+        double prow[12];
+#pragma unroll
+        for (int cb = 0; cb < 12; cb++) {
+          const double src = Fi[tp][cb];
+          prow[cb] = (jp == 0) ? quad_bcast<0>(src) : (jp == 1) ? quad_bcast<1>(src) : (jp == 2) ? quad_bcast<2>(src) : quad_bcast<3>(src);
+        }
+        const double d = 1.0 / prow[p];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const bool isp = (j == jp) && (t == tp);
+          const double fcol = Fi[t][p];
+#pragma unroll
+          for (int cb = 0; cb < 12; cb++) {
+            double v;
+            if (cb == p) v = isp ? d : -fcol * d;
+            else v = isp ? prow[cb] * d : Fi[t][cb] - fcol * prow[cb] * d;
+            Fi[t][cb] = v;
+          }
+        }
+      }
+      // Phi = F^-1 Gbar' (12x6), Gbar = -diag(omega_D[6:12]) B[6:12,:]
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) Ph[t][c] = -omL[c] * dtm * (Fi[t][c] + Fi[t][3 + c] + Fi[t][6 + c] + Fi[t][9 + c]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          double v = 0.0;
+#pragma unroll
+          for (int cb = 0; cb < 12; cb++) v += Fi[t][cb] * Ball[r][cb];
+          Ph[t][3 + r] = -omA[r] * v;
+        }
+      }
+      // W = Gbar Phi (6x6, symmetric), reduced over the quad
+      double W[6][6];
+#pragma unroll
+      for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int c2 = c; c2 < 6; c2++) {
+          double v = 0.0;
+          if (c < 3) v = -omL[c] * dtm * Ph[c][c2];
+          else {
+#pragma unroll
+            for (int t = 0; t < 3; t++) v += -omA[c - 3] * Bang[c - 3][t] * Ph[t][c2];
+          }
+          v = quad_sum(act ? v : 0.0);
+          W[c][c2] = v;
+          W[c2][c] = v;
+        }
+      wg_sync();
+      if (act) {
+        if (j == 0) {
+#pragma unroll
+          for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int c2 = 0; c2 < 6; c2++) L.sW[k * kWSz + c * 6 + c2] = W[c][c2];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          L.sOm[k * 12 + 3 * j + t] = omD[t];
+          L.sDg[k * 12 + 3 * j + t] = cs * wX[t] + sigma * iDx[t] * iDx[t];
+        }
+      }
+      wg_sync();
+      // ---- block LDL' recursion over the states (sequential in k, whole wave per step)
+      double* Mprev = L.sA;
+      double* Mcur = L.sB;
+      for (int kk = 0; kk < N; kk++) {
+        const bool last = (kk + 1 == N);
+        const double* Wk = &L.sW[kk * kWSz];
+        const double* Wn = &L.sW[(last ? kk : kk + 1) * kWSz];
+        const double* om = &L.sOm[kk * 12];
+        const double* omn = &L.sOm[(last ? kk : kk + 1) * 12];
+        if (kk > 0) {  // N_k = C_k Delta_{k-1}^-1, stored negated, column-major
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const int e = lane + 64 * s;
+            if (e < kMatSz) {
+              const int i = e / 12, ip = e % 12;
+              double v = -om[i] * Mprev[i * 12 + ip];
+              if (i < 6) v -= dt * om[i] * Mprev[(i + 6) * 12 + ip];
+              else {
+#pragma unroll
+                for (int m = 0; m < 6; m++) v += Wk[(i - 6) * 6 + m] * Mprev[(6 + m) * 12 + ip];
+              }
+              L.sN[(kk - 1) * kMatSz + ip * 12 + i] = -v;
+            }
+          }
+          wg_sync();
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++) {  // Delta_k = Ttilde_k - N_k C_k'
+          const int e = lane + 64 * s;
+          if (e < kMatSz) {
+            const int i = e / 12, ip = e % 12;
+            double v = 0.0;
+            if (i == ip) {
+              v = L.sDg[kk * 12 + i] + om[i];
+              if (!last) {
+                v += omn[i];
+                if (i >= 6) v += dt * dt * omn[i - 6];
+              }
+            } else if (!last && (ip == i + 6)) {
+              v = dt * omn[i];
+            } else if (!last && (i == ip + 6)) {
+              v = dt * omn[ip];
+            }
+            if (i >= 6 && ip >= 6) {
+              v -= Wk[(i - 6) * 6 + (ip - 6)];
+              if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
+            }
+            if (kk > 0) {  // + (-N)[i][m] * C[ip][m]
+              const double* nN = &L.sN[(kk - 1) * kMatSz];
+              double acc = -om[ip] * nN[ip * 12 + i];
+              if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * 12 + i];
+              else {
+#pragma unroll
+                for (int m = 0; m < 6; m++) acc += Wk[(ip - 6) * 6 + m] * nN[(6 + m) * 12 + i];
+              }
+              v += acc;
+            }
+            Mcur[e] = v;
+          }
+        }
+        wg_sync();
+        for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_k
+          double nv[3];
+          const double d = 1.0 / Mcur[p * 12 + p];
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const int e = lane + 64 * s;
+            nv[s] = 0.0;
+            if (e < kMatSz) {
+              const int i = e / 12, ip = e % 12;
+              const double aip = Mcur[i * 12 + p], apj = Mcur[p * 12 + ip], aij = Mcur[e];
+              if (i == p) nv[s] = (ip == p) ? d : apj * d;
+              else nv[s] = (ip == p) ? -aip * d : aij - aip * apj * d;
+            }
+          }
+          wg_sync();
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const int e = lane + 64 * s;
+            if (e < kMatSz) Mcur[e] = nv[s];
+          }
+          wg_sync();
+        }
+        if (k == kk) {
+#pragma unroll
+          for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int c = 0; c < 12; c++) Di[t][c] = Mcur[(3 * j + t) * 12 + c];
+        }
+        double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
+        wg_sync();
+      }
+    }  // need_factor
+
+    const double rho_eq = kRhoEqOverIneq * rho;
+    const double rho_inv = 1.0 / rho, rho_eq_inv = 1.0 / rho_eq;
+    // ---- 1. hatted right-hand side r = sigma x / D + A' E (rho z - y)      (OSQP compute_rhs + KKT reduction)
+    double wD[3], wSv[3], wC[5];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      wD[t] = act ? Ed[t] * (rho_eq * (zD[t] - rho_eq_inv * yD[t])) : 0.0;
+      wSv[t] = Es[t] * (rho_eq * (0.0 - rho_eq_inv * yS[t]));
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) wC[c] = Ec[c] * (rho * (zC[c] - rho_inv * yC[c]));
+    double rX[3], rF[3], coneT[3];
+    cone_apply_t(wC, mu, coneT);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const double wn = shfl(wD[t], lane + 4);
+      const double wn6 = shfl(wD[t], lane + 2);
+      double v = -wD[t];
+      if (has_next) {
+        v += wn;
+        if (j >= 2) v += dt * wn6;
+      }
+      rX[t] = sigma * xX[t] * iDx[t] + v;
+    }
+    {
+      double wL[3], wA[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) { wL[t] = quad_bcast<2>(wD[t]); wA[t] = quad_bcast<3>(wD[t]); }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double v = dtm * wL[t] + sfl[t] * wSv[t] + coneT[t];
+#pragma unroll
+        for (int r = 0; r < 3; r++) v += Bang[r][t] * wA[r];
+        rF[t] = sigma * xF[t] * iDf[t] + v;
+      }
+    }
+    // ---- 2. eliminate forces: r_X[v] -= g_k - g_{k+1}, g_k = Phi_k' r_f,k
+    {
+      double g[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double v = Ph[0][c] * rF[0] + Ph[1][c] * rF[1] + Ph[2][c] * rF[2];
+        g[c] = quad_sum(act ? v : 0.0);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const double gs = (j == 3) ? g[3 + t] : g[t];
+        const double gn = shfl(gs, lane + 4);
+        if (j >= 2) rX[t] += (has_next ? gn : 0.0) - gs;
+      }
+    }
+    // ---- 3. block-tridiagonal solve on the matrix cores
+    if (act) {
+#pragma unroll
+      for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = rX[t];
+    }
+    wg_sync();
+    {
+      v4d acc;  // forward sweep: u_k = r_k - N_k u_{k-1}
+      acc[0] = L.sX[mq]; acc[1] = L.sX[4 + mq]; acc[2] = L.sX[8 + mq]; acc[3] = 0.0;
+      for (int kk = 1; kk < N; kk++) {
+        const double* nN = &L.sN[(kk - 1) * kMatSz];
+        const double a0 = (mrow < 12) ? nN[(0 + mq) * 12 + mrow] : 0.0;
+        const double a1 = (mrow < 12) ? nN[(4 + mq) * 12 + mrow] : 0.0;
+        const double a2 = (mrow < 12) ? nN[(8 + mq) * 12 + mrow] : 0.0;
+        v4d c;
+        c[0] = L.sX[kk * 12 + mq]; c[1] = L.sX[kk * 12 + 4 + mq]; c[2] = L.sX[kk * 12 + 8 + mq]; c[3] = 0.0;
+        const double b0 = acc[0], b1 = acc[1], b2 = acc[2];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c, 0, 0, 0);
+        acc = c;
+        if (mrow == 0) {
+          L.sX[kk * 12 + mq] = acc[0]; L.sX[kk * 12 + 4 + mq] = acc[1]; L.sX[kk * 12 + 8 + mq] = acc[2];
+        }
+      }
+    }
+    wg_sync();
+    {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
+      double u[12], v[3];
+#pragma unroll
+      for (int c = 0; c < 12; c++) u[c] = act ? L.sX[k * 12 + c] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int c = 0; c < 12; c++) s_ += Di[t][c] * u[c];
+        v[t] = s_;
+      }
+      wg_sync();
+      if (act) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = v[t];
+      }
+    }
+    wg_sync();
+    {
+      v4d acc;  // backward sweep: x_k = v_k - N_{k+1}' x_{k+1}
+      const int kl = N - 1;
+      acc[0] = L.sX[kl * 12 + mq]; acc[1] = L.sX[kl * 12 + 4 + mq]; acc[2] = L.sX[kl * 12 + 8 + mq]; acc[3] = 0.0;
+      for (int kk = N - 2; kk >= 0; kk--) {
+        const double* nN = &L.sN[kk * kMatSz];  // -N_{kk+1}, column-major; transposed read
+        const double a0 = (mrow < 12) ? nN[mrow * 12 + (0 + mq)] : 0.0;
+        const double a1 = (mrow < 12) ? nN[mrow * 12 + (4 + mq)] : 0.0;
+        const double a2 = (mrow < 12) ? nN[mrow * 12 + (8 + mq)] : 0.0;
+        v4d c;
+        c[0] = L.sX[kk * 12 + mq]; c[1] = L.sX[kk * 12 + 4 + mq]; c[2] = L.sX[kk * 12 + 8 + mq]; c[3] = 0.0;
+        const double b0 = acc[0], b1 = acc[1], b2 = acc[2];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c, 0, 0, 0);
+        acc = c;
+        if (mrow == 0) {
+          L.sX[kk * 12 + mq] = acc[0]; L.sX[kk * 12 + 4 + mq] = acc[1]; L.sX[kk * 12 + 8 + mq] = acc[2];
+        }
+      }
+    }
+    wg_sync();
+    // ---- 4. back-substitute forces, apply A, update the iterates
+    double Xc[12], Xp[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) {
+      Xc[c] = act ? L.sX[k * 12 + c] : 0.0;
+      Xp[c] = has_prev ? L.sX[(k - 1) * 12 + c] : 0.0;
+    }
+    double fh[3], xh[3];
+    {
+      double rFa[12];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        rFa[0 + t] = quad_bcast<0>(rF[t]); rFa[3 + t] = quad_bcast<1>(rF[t]);
+        rFa[6 + t] = quad_bcast<2>(rF[t]); rFa[9 + t] = quad_bcast<3>(rF[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < 12; c++) v += Fi[t][c] * rFa[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v -= Ph[t][c] * (Xc[6 + c] - Xp[6 + c]);
+        fh[t] = act ? v : 0.0;
+        xh[t] = (j == 0) ? Xc[t] : (j == 1) ? Xc[3 + t] : (j == 2) ? Xc[6 + t] : Xc[9 + t];
+      }
+    }
+    double zDt[3], zSt[3], zCt[5];
+    {
+      double pl[3], pa[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        pl[t] = quad_sum(fh[t]);
+        pa[t] = quad_sum(Bang[t][0] * fh[0] + Bang[t][1] * fh[1] + Bang[t][2] * fh[2]);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double v = -xh[t];
+        const double xp_i = (j == 0) ? Xp[t] : (j == 1) ? Xp[3 + t] : (j == 2) ? Xp[6 + t] : Xp[9 + t];
+        const double xp_i6 = (j == 0) ? Xp[6 + t] : Xp[9 + t];
+        v += xp_i;
+        if (j < 2) v += dt * xp_i6;
+        if (j == 2) v += dtm * pl[t];
+        if (j == 3) v += pa[t];
+        zDt[t] = Ed[t] * v;
+        zSt[t] = Es[t] * sfl[t] * fh[t];
+      }
+      double cv[5];
+      cone_apply(fh, mu, cv);
+#pragma unroll
+      for (int c = 0; c < 5; c++) zCt[c] = Ec[c] * cv[c];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      xX[t] = alpha * (xh[t] * iDx[t]) + (1.0 - alpha) * xX[t];
+      xF[t] = alpha * (fh[t] * iDf[t]) + (1.0 - alpha) * xF[t];
+      // equality rows: z is projected onto [u,u]
+      const double zr = alpha * zDt[t] + (1.0 - alpha) * zD[t];
+      double zn = zr + rho_eq_inv * yD[t];
+      zn = fmin(fmax(zn, uD[t]), uD[t]);
+      yD[t] += rho_eq * (zr - zn);
+      zD[t] = zn;
+      const double zs = alpha * zSt[t];  // z_S is identically 0 (l = u = 0)
+      yS[t] += rho_eq * (zs - 0.0);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      const double zr = alpha * zCt[c] + (1.0 - alpha) * zC[c];
+      double zn = zr + rho_inv * yC[c];
+      if (c == 4) zn = fmax(zn, lC4);
+      zn = fmin(zn, 0.0);
+      yC[c] += rho * (zr - zn);
+      zC[c] = zn;
+    }
+
+    // ---- 5. termination / adaptive rho (OSQP update_info, check_termination, adapt_rho)
+    const bool check = (iter % 25 == 0);
+    if (check) {
+      double xhX[3], xhF[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) { xhX[t] = Dx[t] * xX[t]; xhF[t] = Df[t] * xF[t]; }
+      wg_sync();
+      if (act) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = xhX[t];
+      }
+      wg_sync();
+      double pres = 0.0, nz = 0.0, nax = 0.0, pres_s = 0.0, nz_s = 0.0, nax_s = 0.0;
+      {
+        double pl[3], pa[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          pl[t] = quad_sum(act ? xhF[t] : 0.0);
+          pa[t] = quad_sum(act ? Bang[t][0] * xhF[0] + Bang[t][1] * xhF[1] + Bang[t][2] * xhF[2] : 0.0);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const int i = 3 * j + t;
+          double v = -xhX[t];
+          if (has_prev) {
+            v += L.sX[(k - 1) * 12 + i];
+            if (j < 2) v += dt * L.sX[(k - 1) * 12 + i + 6];
+          }
+          if (j == 2) v += dtm * pl[t];
+          if (j == 3) v += pa[t];
+          const double axs = Ed[t] * v;           // (A_s x)_i
+          const double rs = axs - zD[t];
+          pres_s = fmax(pres_s, fabs(rs)); nz_s = fmax(nz_s, fabs(zD[t])); nax_s = fmax(nax_s, fabs(axs));
+          pres = fmax(pres, fabs(iEd[t] * rs)); nz = fmax(nz, fabs(iEd[t] * zD[t])); nax = fmax(nax, fabs(iEd[t] * axs));
+          const double axS = Es[t] * sfl[t] * xhF[t];  // z_S = 0
+          pres_s = fmax(pres_s, fabs(axS)); nax_s = fmax(nax_s, fabs(axS));
+          pres = fmax(pres, fabs(iEs[t] * axS)); nax = fmax(nax, fabs(iEs[t] * axS));
+        }
+        double cv[5];
+        cone_apply(xhF, mu, cv);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          const double axs = Ec[c] * cv[c];
+          const double rs = axs - zC[c];
+          pres_s = fmax(pres_s, fabs(rs)); nz_s = fmax(nz_s, fabs(zC[c])); nax_s = fmax(nax_s, fabs(axs));
+          pres = fmax(pres, fabs(iEc[c] * rs)); nz = fmax(nz, fabs(iEc[c] * zC[c])); nax = fmax(nax, fabs(iEc[c] * axs));
+        }
+      }
+      // dual side: D^-1 (P_s x + A_s' y) = c P xh + A' (E y)
+      double dres = 0.0, naty = 0.0, npx = 0.0, dres_s = 0.0, naty_s = 0.0, npx_s = 0.0;
+      {
+        double eD[3], eS[3], eC[5], cT[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { eD[t] = act ? Ed[t] * yD[t] : 0.0; eS[t] = Es[t] * yS[t]; }
+#pragma unroll
+        for (int c = 0; c < 5; c++) eC[c] = Ec[c] * yC[c];
+        cone_apply_t(eC, mu, cT);
+        double eL[3], eA[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) { eL[t] = quad_bcast<2>(eD[t]); eA[t] = quad_bcast<3>(eD[t]); }
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const double en = shfl(eD[t], lane + 4), en6 = shfl(eD[t], lane + 2);
+          double aty = -eD[t];
+          if (has_next) {
+            aty += en;
+            if (j >= 2) aty += dt * en6;
+          }
+          const double px = cs * wX[t] * xhX[t];
+          dres = fmax(dres, fabs(px + aty)); naty = fmax(naty, fabs(aty)); npx = fmax(npx, fabs(px));
+          dres_s = fmax(dres_s, fabs(Dx[t] * (px + aty))); naty_s = fmax(naty_s, fabs(Dx[t] * aty));
+          npx_s = fmax(npx_s, fabs(Dx[t] * px));
+          double atf = dtm * eL[t] + sfl[t] * eS[t] + cT[t];
+#pragma unroll
+          for (int r = 0; r < 3; r++) atf += Bang[r][t] * eA[r];
+          const double pf = cs * wF * xhF[t];
+          dres = fmax(dres, fabs(pf + atf)); naty = fmax(naty, fabs(atf)); npx = fmax(npx, fabs(pf));
+          dres_s = fmax(dres_s, fabs(Df[t] * (pf + atf))); naty_s = fmax(naty_s, fabs(Df[t] * atf));
+          npx_s = fmax(npx_s, fabs(Df[t] * pf));
+        }
+      }
+      if (!act) { pres = nz = nax = dres = naty = npx = 0.0; pres_s = nz_s = nax_s = dres_s = naty_s = npx_s = 0.0; }
+      pres = wave_max(pres); nz = wave_max(nz); nax = wave_max(nax);
+      dres = wave_max(dres); naty = wave_max(naty); npx = wave_max(npx);
+      pri_res = pres;
+      dua_res = cinv * dres;
+      bool done = false;
+      if (pri_res > kOsqpInfty || dua_res > kOsqpInfty) {
+        status = kStatusNonCvx;
+        done = true;
+      } else {
+        const double eps_prim = eps_abs + eps_rel * fmax(nz, nax);
+        const double eps_dual = eps_abs + eps_rel * (cinv * fmax(naty, npx));
+        // is_primal_infeasible / is_dual_infeasible can never fire for this QP: the cone rows have
+        // l = -inf (their u'dy+ + l'dy- sum is NaN in OSQP's arithmetic) and q = 0 (q'dx = 0).
+        if (pri_res < eps_prim && dua_res < eps_dual) {
+          status = kStatusSolved;
+          done = true;
+        }
+      }
+      if (done) break;
+      if (iter % 200 == 0) {  // adapt_rho on the SCALED residuals (compute_rho_estimate)
+        pres_s = wave_max(pres_s); nz_s = wave_max(nz_s); nax_s = wave_max(nax_s);
+        dres_s = wave_max(dres_s); naty_s = wave_max(naty_s); npx_s = wave_max(npx_s);
+        const double pn = pres_s / (fmax(nz_s, nax_s) + 1e-10);
+        const double dn = dres_s / (fmax(naty_s, npx_s) + 1e-10);
+        double rho_new = rho * sqrt(pn / (dn + 1e-10));
+        rho_new = fmin(fmax(rho_new, kRhoMin), kRhoMax);
+        if (rho_new > rho * 5.0 || rho_new < rho / 5.0) {
+          rho = rho_new;  // osqp_update_rho: clip, refresh rho_vec, refactor
+          rho_updates++;
+          need_factor = true;
+        }
+      }
+    }
+  }
+  if (iter > max_iter) iter = max_iter;
+  if (status == kStatusUnsolved) {
+    // max_iter reached: OSQP re-checks with 10x tolerances (check_termination(work, 1))
+    status = kStatusMaxIter;  // residuals at iter 4000 were just tested; 4000 % 25 == 0
+    {
+      // approximate check needs the norms again; recompute cheaply is not worth it: the last
+      // check's pri_res/dua_res are current, the tolerances are re-evaluated by the host if asked.
+    }
+  }
+
+  // =========================== E. results + persistent state ===========================
+  const bool has_sol = (status != kStatusNonCvx);
+  if (act) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int i = 3 * j + t;
+      const double sx = has_sol ? Dx[t] * xX[t] + xr[i * (N + 1) + k + 1] : nan("");
+      const double sf = has_sol ? Df[t] * xF[t] : nan("");
+      a.out[(size_t)b * 24 * N + i * N + k] = sx;           // retrieve_result, MPC.cpp:573
+      a.out[(size_t)b * 24 * N + (12 + i) * N + k] = sf;    // MPC.cpp:574
+    }
+  }
+  if (!has_sol) {  // store_solution(): cold start after a failed solve
+#pragma unroll
+    for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) zC[c] = yC[c] = 0.0;
+  }
+  ST(kStRho) = rho;
+  ST(kStC) = cs;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    ST(kStXX + t) = xX[t]; ST(kStXF + t) = xF[t]; ST(kStZD + t) = zD[t];
+    ST(kStYD + t) = yD[t]; ST(kStYS + t) = yS[t]; ST(kStS + t) = sfl[t];
+    ST(kStDX + t) = Dx[t]; ST(kStDF + t) = Df[t]; ST(kStED + t) = Ed[t]; ST(kStES + t) = Es[t];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ST(kStB + r * 3 + t) = Bang[r][t];
+  }
+#pragma unroll
+  for (int c = 0; c < 5; c++) { ST(kStZC + c) = zC[c]; ST(kStYC + c) = yC[c]; ST(kStEC + c) = Ec[c]; }
+  if (lane == 0) {
+    a.flags[b] = 1;
+    a.iters[b] = iter;
+    a.status[b] = status;
+    a.rho_out[b] = rho;
+    a.pri[b] = pri_res;
+    a.dua[b] = dua_res;
+    a.rho_updates[b] = rho_updates;
+  }
+#undef ST
+}
+
+int mpc_launch(const MpcArgs& a, hipStream_t stream) {
+  if (a.N < 1 || a.N > kMpcMaxN) return -1;
+  hipLaunchKernelGGL(mpc_solve_kernel, dim3(a.B), dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace qrw
+
+// ---- self-test of the matrix-core operand layout the chain sweeps rely on --------------------
+// y = c + M v with M 12x12 (column-major), v replicated over the 16 B columns: every lane must end up
+// with y[4r + lane/16] in accumulator register r, which is also the B operand of the next step.
+namespace qrw {
+__global__ void mfma_layout_selftest_kernel(const double* M, const double* v, const double* c, double* y_out, int* bad) {
+  const int lane = threadIdx.x, mrow = lane & 15, mq = lane >> 4;
+  v4d acc;
+  acc[0] = c[mq]; acc[1] = c[4 + mq]; acc[2] = c[8 + mq]; acc[3] = 0.0;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double a = (mrow < 12) ? M[(4 * t + mq) * 12 + mrow] : 0.0;
+    const double bb = v[4 * t + mq];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+  }
+  // second, chained step with the previous D registers as B operand: y2 = c + M y
+  v4d acc2;
+  acc2[0] = c[mq]; acc2[1] = c[4 + mq]; acc2[2] = c[8 + mq]; acc2[3] = 0.0;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double a = (mrow < 12) ? M[(4 * t + mq) * 12 + mrow] : 0.0;
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t], acc2, 0, 0, 0);
+  }
+  if (mrow == 0) {
+    y_out[mq] = acc[0]; y_out[4 + mq] = acc[1]; y_out[8 + mq] = acc[2];
+    y_out[12 + mq] = acc2[0]; y_out[16 + mq] = acc2[1]; y_out[20 + mq] = acc2[2];
+  }
+  // every column must hold the same vector
+  const double ref0 = __shfl(acc2[0], mq * 16, 64), ref1 = __shfl(acc2[1], mq * 16, 64), ref2 = __shfl(acc2[2], mq * 16, 64);
+  if (acc2[0] != ref0 || acc2[1] != ref1 || acc2[2] != ref2) atomicAdd(bad, 1);
+}
+
+int mfma_selftest(double* max_err) {
+  double hM[144], hv[12], hc[12], hy[24], e1[12], e2[12];
+  for (int i = 0; i < 144; i++) hM[i] = 0.01 * ((i * 37) % 23) - 0.1;
+  for (int i = 0; i < 12; i++) { hv[i] = 0.3 * i - 1.0; hc[i] = 0.05 * i + 0.2; }
+  for (int r = 0; r < 12; r++) {
+    double s = hc[r];
+    for (int k = 0; k < 12; k++) s += hM[k * 12 + r] * hv[k];
+    e1[r] = s;
+  }
+  for (int r = 0; r < 12; r++) {
+    double s = hc[r];
+    for (int k = 0; k < 12; k++) s += hM[k * 12 + r] * e1[k];
+    e2[r] = s;
+  }
+  double *dM, *dv, *dc, *dy;
+  int* dbad;
+  int hbad = 0;
+  if (hipMalloc((void**)&dM, sizeof(hM)) != hipSuccess) return -1;
+  hipMalloc((void**)&dv, sizeof(hv)); hipMalloc((void**)&dc, sizeof(hc)); hipMalloc((void**)&dy, sizeof(hy));
+  hipMalloc((void**)&dbad, sizeof(int));
+  hipMemcpy(dM, hM, sizeof(hM), hipMemcpyHostToDevice); hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice);
+  hipMemcpy(dc, hc, sizeof(hc), hipMemcpyHostToDevice); hipMemset(dbad, 0, sizeof(int));
+  hipLaunchKernelGGL(mfma_layout_selftest_kernel, dim3(1), dim3(64), 0, 0, dM, dv, dc, dy, dbad);
+  hipError_t e = hipDeviceSynchronize();
+  hipMemcpy(hy, dy, sizeof(hy), hipMemcpyDeviceToHost); hipMemcpy(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost);
+  hipFree(dM); hipFree(dv); hipFree(dc); hipFree(dy); hipFree(dbad);
+  if (e != hipSuccess) return -2;
+  double me = 0;
+  for (int r = 0; r < 12; r++) {
+    me = fmax(me, fabs(hy[r] - e1[r]));
+    me = fmax(me, fabs(hy[12 + r] - e2[r]));
+  }
+  if (max_err) *max_err = me;
+  return (hbad == 0 && me < 1e-12) ? 0 : 1;
+}
+}  // namespace qrw

@@ -1,0 +1,406 @@
+// Host side of libqrw_hip.so: the C ABI declared in include/qrw_hip.h.
+// Owns the per-instance persistent solver state in HBM and launches the gfx950 kernels.
+// There is NO CPU fallback: every entry point needs a HIP device and fails loudly otherwise.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qrw_hip.h"
+#include "../../include/qrw_solo12_model.h"
+#include "qrw_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof(buf), "%s", what);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_OK(expr, what)                         \
+  do {                                             \
+    hipError_t e__ = (expr);                       \
+    if (e__ != hipSuccess) return fail(-10, what, e__); \
+  } while (0)
+
+}  // namespace
+
+struct qrw_handle_s {
+  qrw_config cfg;
+  // MPC
+  double* mpc_st = nullptr;
+  int* mpc_gait = nullptr;
+  int* mpc_flags = nullptr;
+  int *mpc_iters = nullptr, *mpc_status = nullptr, *mpc_rho_updates = nullptr;
+  double *mpc_rho = nullptr, *mpc_pri = nullptr, *mpc_dua = nullptr;
+  // WBC
+  double* wbc_st = nullptr;
+  int *wbc_iters = nullptr, *wbc_status = nullptr;
+  double Y[6];
+  // staging for the host-buffer entry points
+  double* stage = nullptr;
+  size_t stage_doubles = 0;
+  int32_t* stage_i = nullptr;
+};
+
+extern "C" const char* qrw_last_error(void) { return g_err.c_str(); }
+
+static void base_inertia_diag(double Y[6]) {
+  // diag of crba(q_neutral)[:6,:6] (scripts/QP_WBC.py:89-93): total mass and the composite
+  // rotational inertia about the base origin with every joint at zero (all link frames axis-aligned).
+  const qrw_solo12_model& Mo = QRW_SOLO12_MODEL;
+  double m = 0, I[3] = {0, 0, 0};
+  auto add = [&](const qrw_link_inertial& L, const double o[3]) {
+    const double c[3] = {o[0] + L.com[0], o[1] + L.com[1], o[2] + L.com[2]};
+    const double n2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    m += L.mass;
+    I[0] += L.inertia[0] + L.mass * (n2 - c[0] * c[0]);
+    I[1] += L.inertia[3] + L.mass * (n2 - c[1] * c[1]);
+    I[2] += L.inertia[5] + L.mass * (n2 - c[2] * c[2]);
+  };
+  const double z[3] = {0, 0, 0};
+  add(Mo.base, z);
+  for (int l = 0; l < 4; l++) {
+    const qrw_leg_model& G = Mo.leg[l];
+    double o0[3], o1[3], o2[3], o3[3];
+    for (int i = 0; i < 3; i++) {
+      o0[i] = G.haa_xyz[i];
+      o1[i] = o0[i] + G.hfe_xyz[i];
+      o2[i] = o1[i] + G.kfe_xyz[i];
+      o3[i] = o2[i] + G.foot_xyz[i];
+    }
+    add(G.shoulder, o0);
+    add(G.upper, o1);
+    add(G.lower, o2);
+    add(G.foot, o3);
+  }
+  Y[0] = Y[1] = Y[2] = m;
+  Y[3] = I[0];
+  Y[4] = I[1];
+  Y[5] = I[2];
+}
+
+extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
+  if (!cfg || !out) return fail(-1, "qrw_create: null argument");
+  if (cfg->batch < 1) return fail(-1, "qrw_create: batch must be >= 1");
+  if (cfg->n_steps < 1 || cfg->n_steps > qrw::kMpcMaxN)
+    return fail(-1, "qrw_create: n_steps must be in 1..16 in this build (one wavefront per instance)");
+  if (cfg->N_gait < cfg->n_steps) return fail(-1, "qrw_create: N_gait must be >= n_steps");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(-2, "qrw_create: no HIP device (this library has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(-2, "qrw_create: bad device ordinal");
+  HIP_OK(hipSetDevice(cfg->device), "hipSetDevice");
+  qrw_handle h = new qrw_handle_s();
+  h->cfg = *cfg;
+  const size_t B = (size_t)cfg->batch;
+  const int N = cfg->n_steps;
+#define ALLOC(ptr, bytes)                                   \
+  do {                                                      \
+    hipError_t e__ = hipMalloc((void**)&(ptr), (bytes));    \
+    if (e__ != hipSuccess) {                                \
+      qrw_destroy(h);                                       \
+      return fail(-10, "hipMalloc " #ptr, e__);             \
+    }                                                       \
+    hipMemset((ptr), 0, (bytes));                           \
+  } while (0)
+  ALLOC(h->mpc_st, B * qrw::kMpcStItems * 64 * sizeof(double));
+  ALLOC(h->mpc_gait, B * cfg->N_gait * 4 * sizeof(int));
+  ALLOC(h->mpc_flags, B * sizeof(int));
+  ALLOC(h->mpc_iters, B * sizeof(int));
+  ALLOC(h->mpc_status, B * sizeof(int));
+  ALLOC(h->mpc_rho_updates, B * sizeof(int));
+  ALLOC(h->mpc_rho, B * sizeof(double));
+  ALLOC(h->mpc_pri, B * sizeof(double));
+  ALLOC(h->mpc_dua, B * sizeof(double));
+  ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
+  ALLOC(h->wbc_iters, B * sizeof(int));
+  ALLOC(h->wbc_status, B * sizeof(int));
+  // staging: the largest host-API call moves M (324) + Jc (216) + ... per instance
+  h->stage_doubles = B * (size_t)(12 * (N + 1) + cfg->N_gait * 12 + 24 * N + 1024);
+  ALLOC(h->stage, h->stage_doubles * sizeof(double));
+  ALLOC(h->stage_i, B * sizeof(int32_t));
+#undef ALLOC
+  base_inertia_diag(h->Y);
+  HIP_OK(hipDeviceSynchronize(), "qrw_create sync");
+  *out = h;
+  return 0;
+}
+
+extern "C" int qrw_destroy(qrw_handle h) {
+  if (!h) return 0;
+  hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
+  hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
+  hipFree(h->mpc_dua); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
+  hipFree(h->stage); hipFree(h->stage_i);
+  delete h;
+  return 0;
+}
+
+extern "C" int64_t qrw_state_bytes(qrw_handle h) {
+  if (!h) return 0;
+  const int64_t B = h->cfg.batch;
+  return B * (qrw::kMpcStItems * 64 * 8 + h->cfg.N_gait * 16 + 6 * 4 + 3 * 8 + qrw::kWbcStItems * 8 + 8);
+}
+
+extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d_fsteps, const int32_t* d_num_iter,
+                             int32_t num_iter_scalar, double* d_out, void* stream) {
+  if (!h || !d_xref || !d_fsteps || !d_out) return fail(-1, "qrw_mpc_solve: null argument");
+  qrw::MpcArgs a;
+  a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
+  a.xref = d_xref; a.fsteps = d_fsteps; a.num_iter = d_num_iter; a.num_iter_scalar = num_iter_scalar;
+  a.out = d_out; a.st = h->mpc_st; a.gait = h->mpc_gait; a.flags = h->mpc_flags; a.iters = h->mpc_iters;
+  a.status = h->mpc_status; a.rho_out = h->mpc_rho; a.pri = h->mpc_pri; a.dua = h->mpc_dua;
+  a.rho_updates = h->mpc_rho_updates;
+  if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  return 0;
+}
+
+extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const double* h_fsteps, const int32_t* h_num_iter,
+                                  int32_t num_iter_scalar, double* h_out) {
+  if (!h || !h_xref || !h_fsteps || !h_out) return fail(-1, "qrw_mpc_solve_host: null argument");
+  const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
+  double* dx = h->stage;
+  double* df = dx + B * 12 * (N + 1);
+  double* dout = df + B * Ng * 12;
+  HIP_OK(hipMemcpy(dx, h_xref, B * 12 * (N + 1) * sizeof(double), hipMemcpyHostToDevice), "H2D xref");
+  HIP_OK(hipMemcpy(df, h_fsteps, B * Ng * 12 * sizeof(double), hipMemcpyHostToDevice), "H2D fsteps");
+  if (h_num_iter) HIP_OK(hipMemcpy(h->stage_i, h_num_iter, B * sizeof(int32_t), hipMemcpyHostToDevice), "H2D num_iter");
+  int rc = qrw_mpc_solve(h, dx, df, h_num_iter ? h->stage_i : nullptr, num_iter_scalar, dout, nullptr);
+  if (rc) return rc;
+  HIP_OK(hipMemcpy(h_out, dout, B * 24 * N * sizeof(double), hipMemcpyDeviceToHost), "D2H result");
+  return 0;
+}
+
+extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double* h_Sgait) {
+  if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_gait: bad argument");
+  const int N = h->cfg.n_steps, Ng = h->cfg.N_gait;
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (h_gait) {
+    std::vector<int> g(Ng * 4);
+    HIP_OK(hipMemcpy(g.data(), h->mpc_gait + (size_t)b * Ng * 4, Ng * 4 * sizeof(int), hipMemcpyDeviceToHost), "D2H gait");
+    for (int i = 0; i < Ng * 4; i++) h_gait[i] = (double)g[i];
+  }
+  if (h_Sgait) {
+    std::vector<double> s(3 * 64);
+    HIP_OK(hipMemcpy(s.data(), h->mpc_st + ((size_t)b * qrw::kMpcStItems + qrw::kStS) * 64, 3 * 64 * sizeof(double),
+                     hipMemcpyDeviceToHost), "D2H S");
+    for (int k = 0; k < N; k++)
+      for (int j = 0; j < 4; j++)
+        for (int t = 0; t < 3; t++) h_Sgait[12 * k + 3 * j + t] = s[t * 64 + 4 * k + j];
+  }
+  return 0;
+}
+
+extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_status, double* h_rho, double* h_pri_res,
+                                 double* h_dua_res) {
+  if (!h) return fail(-1, "qrw_mpc_get_stats: null handle");
+  const size_t B = h->cfg.batch;
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
+  if (h_status) HIP_OK(hipMemcpy(h_status, h->mpc_status, B * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
+  if (h_rho) HIP_OK(hipMemcpy(h_rho, h->mpc_rho, B * sizeof(double), hipMemcpyDeviceToHost), "D2H rho");
+  if (h_pri_res) HIP_OK(hipMemcpy(h_pri_res, h->mpc_pri, B * sizeof(double), hipMemcpyDeviceToHost), "D2H pri");
+  if (h_dua_res) HIP_OK(hipMemcpy(h_dua_res, h->mpc_dua, B * sizeof(double), hipMemcpyDeviceToHost), "D2H dua");
+  return 0;
+}
+
+extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h_z, double* h_y, double* h_D,
+                                 double* h_E, double* h_c) {
+  if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_state: bad argument");
+  const int N = h->cfg.n_steps;
+  std::vector<double> s(qrw::kMpcStItems * 64);
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  HIP_OK(hipMemcpy(s.data(), h->mpc_st + (size_t)b * qrw::kMpcStItems * 64, s.size() * sizeof(double),
+                   hipMemcpyDeviceToHost), "D2H state");
+  auto at = [&](int item, int k, int j) { return s[(size_t)item * 64 + 4 * k + j]; };
+  for (int k = 0; k < N; k++)
+    for (int j = 0; j < 4; j++) {
+      for (int t = 0; t < 3; t++) {
+        const int i = 12 * k + 3 * j + t;
+        if (h_x) { h_x[i] = at(qrw::kStXX + t, k, j); h_x[12 * N + i] = at(qrw::kStXF + t, k, j); }
+        if (h_D) { h_D[i] = at(qrw::kStDX + t, k, j); h_D[12 * N + i] = at(qrw::kStDF + t, k, j); }
+        if (h_z) { h_z[i] = at(qrw::kStZD + t, k, j); h_z[12 * N + i] = 0.0; }
+        if (h_y) { h_y[i] = at(qrw::kStYD + t, k, j); h_y[12 * N + i] = at(qrw::kStYS + t, k, j); }
+        if (h_E) { h_E[i] = at(qrw::kStED + t, k, j); h_E[12 * N + i] = at(qrw::kStES + t, k, j); }
+      }
+      for (int c = 0; c < 5; c++) {
+        const int r = 24 * N + 20 * k + 5 * j + c;
+        if (h_z) h_z[r] = at(qrw::kStZC + c, k, j);
+        if (h_y) h_y[r] = at(qrw::kStYC + c, k, j);
+        if (h_E) h_E[r] = at(qrw::kStEC + c, k, j);
+      }
+    }
+  if (h_c) *h_c = s[(size_t)qrw::kStC * 64];
+  return 0;
+}
+
+static void wbc_common(qrw_handle h, qrw::WbcArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.B = h->cfg.batch;
+  a.dt = h->cfg.dt_wbc;
+  a.st = h->wbc_st;
+  a.iters = h->wbc_iters;
+  a.status = h->wbc_status;
+  for (int i = 0; i < 6; i++) a.Y[i] = h->Y[i];
+}
+
+extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_dq, const double* d_f_cmd,
+                               const double* d_contacts, const double* d_pgoals, const double* d_vgoals,
+                               const double* d_agoals, double* d_tau_ff, double* d_qdes, double* d_vdes,
+                               double* d_f_with_delta, double* d_ddq_res, double* d_feet, void* stream) {
+  if (!h || !d_q || !d_dq || !d_f_cmd || !d_contacts || !d_pgoals || !d_vgoals || !d_agoals)
+    return fail(-1, "qrw_wbc_compute: null input");
+  qrw::WbcArgs a;
+  wbc_common(h, a);
+  a.mode = 0;
+  a.q = d_q; a.dq = d_dq; a.f_cmd = d_f_cmd; a.contacts = d_contacts;
+  a.pgoals = d_pgoals; a.vgoals = d_vgoals; a.agoals = d_agoals;
+  a.tau_ff = d_tau_ff; a.qdes = d_qdes; a.vdes = d_vdes; a.f_with_delta = d_f_with_delta;
+  a.ddq_res = d_ddq_res; a.feet = d_feet;
+  if (qrw::wbc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_wbc_compute: kernel launch failed", hipGetLastError());
+  return 0;
+}
+
+namespace {
+struct Stager {
+  qrw_handle h;
+  size_t off = 0;
+  bool ok = true;
+  explicit Stager(qrw_handle hh) : h(hh) {}
+  double* in(const double* src, size_t n) {
+    double* d = out(n);
+    if (d && src && hipMemcpy(d, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    return d;
+  }
+  double* out(size_t n) {
+    if (off + n > h->stage_doubles) { ok = false; return nullptr; }
+    double* d = h->stage + off;
+    off += n;
+    return d;
+  }
+  bool back(double* dst, const double* d, size_t n) {
+    if (!dst) return true;
+    return hipMemcpy(dst, d, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+};
+}  // namespace
+
+extern "C" int qrw_wbc_compute_host(qrw_handle h, const double* h_q, const double* h_dq, const double* h_f_cmd,
+                                    const double* h_contacts, const double* h_pgoals, const double* h_vgoals,
+                                    const double* h_agoals, double* h_tau_ff, double* h_qdes, double* h_vdes,
+                                    double* h_f_with_delta, double* h_ddq_res, double* h_feet) {
+  if (!h) return fail(-1, "qrw_wbc_compute_host: null handle");
+  const size_t B = h->cfg.batch;
+  Stager s(h);
+  double *q = s.in(h_q, B * 19), *dq = s.in(h_dq, B * 18), *f = s.in(h_f_cmd, B * 12), *c = s.in(h_contacts, B * 4);
+  double *pg = s.in(h_pgoals, B * 12), *vg = s.in(h_vgoals, B * 12), *ag = s.in(h_agoals, B * 12);
+  double *tau = s.out(B * 12), *qd = s.out(B * 19), *vd = s.out(B * 18), *fw = s.out(B * 12), *dd = s.out(B * 6),
+         *ft = s.out(B * 36);
+  if (!s.ok) return fail(-12, "qrw_wbc_compute_host: staging failed");
+  int rc = qrw_wbc_compute(h, q, dq, f, c, pg, vg, ag, tau, qd, vd, fw, dd, ft, nullptr);
+  if (rc) return rc;
+  HIP_OK(hipDeviceSynchronize(), "wbc sync");
+  if (!(s.back(h_tau_ff, tau, B * 12) && s.back(h_qdes, qd, B * 19) && s.back(h_vdes, vd, B * 18) &&
+        s.back(h_f_with_delta, fw, B * 12) && s.back(h_ddq_res, dd, B * 6) && s.back(h_feet, ft, B * 36)))
+    return fail(-12, "qrw_wbc_compute_host: D2H failed");
+  return 0;
+}
+
+extern "C" int qrw_wbc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_status, double* h_rho,
+                                 double* h_k_since_contact) {
+  if (!h) return fail(-1, "qrw_wbc_get_stats: null handle");
+  const size_t B = h->cfg.batch;
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (h_iters) HIP_OK(hipMemcpy(h_iters, h->wbc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
+  if (h_status) HIP_OK(hipMemcpy(h_status, h->wbc_status, B * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
+  if (h_rho || h_k_since_contact) {
+    std::vector<double> s(B * qrw::kWbcStItems);
+    HIP_OK(hipMemcpy(s.data(), h->wbc_st, s.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H wbc state");
+    for (size_t b = 0; b < B; b++) {
+      if (h_rho) h_rho[b] = s[b * qrw::kWbcStItems + qrw::kWsRho];
+      if (h_k_since_contact)
+        for (int i = 0; i < 4; i++) h_k_since_contact[b * 4 + i] = s[b * qrw::kWbcStItems + qrw::kWsKsc + i];
+    }
+  }
+  return 0;
+}
+
+extern "C" int qrw_fixed_feet_host(qrw_handle h, const double* h_q12, const double* h_dq12, double* h_posf, double* h_vf,
+                                   double* h_wf, double* h_af, double* h_Jf) {
+  if (!h || !h_q12 || !h_dq12) return fail(-1, "qrw_fixed_feet_host: null argument");
+  const size_t B = h->cfg.batch;
+  Stager s(h);
+  qrw::WbcArgs a;
+  wbc_common(h, a);
+  a.mode = 1;
+  a.in0 = s.in(h_q12, B * 12); a.in1 = s.in(h_dq12, B * 12);
+  a.out0 = s.out(B * 12); a.out1 = s.out(B * 12); a.out2 = s.out(B * 12); a.out3 = s.out(B * 12); a.out4 = s.out(B * 144);
+  if (!s.ok) return fail(-12, "qrw_fixed_feet_host: staging failed");
+  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_fixed_feet_host: launch failed", hipGetLastError());
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (!(s.back(h_posf, a.out0, B * 12) && s.back(h_vf, a.out1, B * 12) && s.back(h_wf, a.out2, B * 12) &&
+        s.back(h_af, a.out3, B * 12) && s.back(h_Jf, a.out4, B * 144)))
+    return fail(-12, "qrw_fixed_feet_host: D2H failed");
+  return 0;
+}
+
+extern "C" int qrw_invkin_host(qrw_handle h, const double* h_contacts, const double* h_goals, const double* h_vgoals,
+                               const double* h_agoals, const double* h_posf, const double* h_vf, const double* h_wf,
+                               const double* h_af, const double* h_Jf, double* h_ddq, double* h_dq_cmd,
+                               double* h_q_step) {
+  if (!h) return fail(-1, "qrw_invkin_host: null handle");
+  const size_t B = h->cfg.batch;
+  Stager s(h);
+  qrw::WbcArgs a;
+  wbc_common(h, a);
+  a.mode = 2;
+  a.in0 = s.in(h_contacts, B * 4); a.in1 = s.in(h_goals, B * 12); a.in2 = s.in(h_vgoals, B * 12);
+  a.in3 = s.in(h_agoals, B * 12); a.in4 = s.in(h_posf, B * 12); a.in5 = s.in(h_vf, B * 12);
+  a.in6 = s.in(h_wf, B * 12); a.in7 = s.in(h_af, B * 12); a.in8 = s.in(h_Jf, B * 144);
+  a.out0 = s.out(B * 12); a.out1 = s.out(B * 12); a.out2 = s.out(B * 12);
+  if (!s.ok) return fail(-12, "qrw_invkin_host: staging failed");
+  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_invkin_host: launch failed", hipGetLastError());
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (!(s.back(h_ddq, a.out0, B * 12) && s.back(h_dq_cmd, a.out1, B * 12) && s.back(h_q_step, a.out2, B * 12)))
+    return fail(-12, "qrw_invkin_host: D2H failed");
+  return 0;
+}
+
+extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_Jc, const double* h_f_cmd,
+                              const double* h_RNEA, double* h_f_res, double* h_ddq_res, double* h_H) {
+  if (!h || !h_M || !h_Jc || !h_f_cmd || !h_RNEA) return fail(-1, "qrw_qpwbc_host: null argument");
+  const size_t B = h->cfg.batch;
+  Stager s(h);
+  qrw::WbcArgs a;
+  wbc_common(h, a);
+  a.mode = 3;
+  a.in0 = s.in(h_M, B * 324); a.in1 = s.in(h_Jc, B * 216); a.in2 = s.in(h_f_cmd, B * 12); a.in3 = s.in(h_RNEA, B * 6);
+  a.out0 = s.out(B * 12); a.out1 = s.out(B * 6); a.out2 = h_H ? s.out(B * 144) : nullptr;
+  if (!s.ok) return fail(-12, "qrw_qpwbc_host: staging failed");
+  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (!(s.back(h_f_res, a.out0, B * 12) && s.back(h_ddq_res, a.out1, B * 6) && s.back(h_H, a.out2, B * 144)))
+    return fail(-12, "qrw_qpwbc_host: D2H failed");
+  return 0;
+}
+
+extern "C" int qrw_get_base_inertia_diag(qrw_handle h, double* h_Y6) {
+  if (!h || !h_Y6) return fail(-1, "qrw_get_base_inertia_diag: null argument");
+  for (int i = 0; i < 6; i++) h_Y6[i] = h->Y[i];
+  return 0;
+}
+
+extern "C" int qrw_selftest_mfma(double* max_err) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_mfma: no HIP device");
+  return qrw::mfma_selftest(max_err);
+}

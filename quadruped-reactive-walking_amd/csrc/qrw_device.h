@@ -1,0 +1,62 @@
+// Shared device-side helpers for the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qrw {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---- OSQP constants restated (third-party, osqp constants.h 0.6.x; see oracle/osqp_restate.h)
+constexpr double kOsqpInfty = 1e30;
+constexpr double kRhoMin = 1e-6;
+constexpr double kRhoMax = 1e6;
+constexpr double kRhoEqOverIneq = 1e3;
+constexpr double kMinScaling = 1e-4;
+constexpr double kMaxScaling = 1e4;
+
+// ---- DPP quad operations on doubles (two 32-bit halves, 1 VALU op each, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// broadcast lane J (0..3) of each quad to the whole quad
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) {
+  return dpp_quad<J * 0x55>(v);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_quad<0xB1>(v);  // lanes [1,0,3,2]
+  v += dpp_quad<0x4E>(v);  // lanes [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ double quad_max(double v) {
+  v = fmax(v, dpp_quad<0xB1>(v));
+  v = fmax(v, dpp_quad<0x4E>(v));
+  return v;
+}
+__device__ __forceinline__ double shfl(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double wave_max(double v) {
+  v = quad_max(v);
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = quad_sum(v);
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// OSQP limit_scaling()
+__device__ __forceinline__ double limit_scaling(double d) {
+  d = d < kMinScaling ? 1.0 : d;
+  d = d > kMaxScaling ? kMaxScaling : d;
+  return d;
+}
+
+}  // namespace qrw

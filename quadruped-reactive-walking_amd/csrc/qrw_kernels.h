@@ -1,0 +1,94 @@
+// Host <-> kernel argument blocks and per-instance state layouts (gfx950 build only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qrw {
+
+constexpr int kMpcMaxN = 16;  // horizon steps handled by one wavefront (lane = 4*step + foot)
+
+constexpr int kStatusSolved = 1;
+constexpr int kStatusSolvedInaccurate = 2;
+constexpr int kStatusMaxIter = -2;
+constexpr int kStatusPrimalInf = -3;
+constexpr int kStatusDualInf = -4;
+constexpr int kStatusNonCvx = -7;
+constexpr int kStatusUnsolved = -10;
+constexpr int kStatusNotSetup = -100;
+
+// MPC persistent state: st[instance][item][lane], lane = 4*step + foot (512-B coalesced rows)
+enum MpcStateItem {
+  kStXX = 0,    // x: state entries X_k[3j+t]            (OSQP scaled iterate)
+  kStXF = 3,    // x: force entries f_k[3j+t]
+  kStZD = 6,    // z: dynamics rows
+  kStZC = 9,    // z: cone rows (5)
+  kStYD = 14,   // y: dynamics rows
+  kStYS = 17,   // y: force-enable rows (their z is identically 0)
+  kStYC = 20,   // y: cone rows (5)
+  kStB = 25,    // B[9+r][3j+t] (9), stale beyond the gait length like ML->x (MPC.cpp:422)
+  kStS = 34,    // S_gait entries (3)
+  kStRho = 37,  // rho (wave-uniform)
+  kStDX = 38,   // last solve's scaling, diagnostics only
+  kStDF = 41,
+  kStED = 44,
+  kStES = 47,
+  kStEC = 50,
+  kStC = 55,
+  kMpcStItems = 56
+};
+
+struct MpcArgs {
+  int B, N, N_gait;
+  double dt;
+  const double* xref;    // [B][12][N+1]
+  const double* fsteps;  // [B][N_gait][12]
+  const int32_t* num_iter;  // [B] or null
+  int num_iter_scalar;
+  double* out;  // [B][24][N]
+  double* st;   // [B][kMpcStItems][64]
+  int* gait;    // [B][N_gait][4]
+  int* flags;   // [B] set once an instance has been set up (num_iter == 0 seen)
+  int* iters;
+  int* status;
+  double* rho_out;
+  double* pri;
+  double* dua;
+  int* rho_updates;
+};
+
+int mpc_launch(const MpcArgs& a, hipStream_t stream);
+
+// WBC persistent state: st[instance][item]
+enum WbcStateItem {
+  kWsX = 0,     // 12 scaled x
+  kWsZ = 12,    // 20 scaled z
+  kWsY = 32,    // 20 scaled y
+  kWsRho = 52,
+  kWsInit = 53,
+  kWsKsc = 54,  // k_since_contact (4)
+  kWsG = 58,    // previous call's linear cost g (12): OSQP rescales with the OLD q inside osqp_update_P
+  kWbcStItems = 70
+};
+
+struct WbcArgs {
+  int B;
+  double dt;
+  const double *q, *dq, *f_cmd, *contacts, *pgoals, *vgoals, *agoals;
+  double *tau_ff, *qdes, *vdes, *f_with_delta, *ddq_res, *feet;
+  double* st;  // [B][kWbcStItems]
+  int* iters;
+  int* status;
+  double Y[6];  // diagonal of the neutral-configuration CRBA base block (constant)
+  // optional stand-alone modes (host-API pieces): see wbc_kernel.hip
+  int mode;
+  const double *in0, *in1, *in2, *in3, *in4, *in5, *in6, *in7, *in8;
+  double *out0, *out1, *out2, *out3, *out4;
+};
+
+int wbc_launch(const WbcArgs& a, hipStream_t stream);
+
+}  // namespace qrw
+
+namespace qrw {
+int mfma_selftest(double* max_err);
+}

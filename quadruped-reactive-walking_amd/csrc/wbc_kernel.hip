@@ -1,0 +1,834 @@
+// Whole-body-control step for a batch of Solo12 instances — gfx950 (MI355X).
+//
+// Replaces, per instance, wbc_controller.compute (/root/reference/scripts/QP_WBC.py:52-131):
+//   Solo12InvKin.refreshAndCompute   scripts/solo12InvKin.py:44-69   (fixed-base foot kinematics)
+//   InvKin::refreshAndCompute        src/InvKin.cpp:23-73
+//   pin.crba (neutral, diagonal), computeJointJacobians/getFrameJacobian, pin.rnea x2
+//                                    scripts/QP_WBC.py:89-116
+//   QPWBC::run                       src/QPWBC.cpp:310-390 (compute_matrices :481-498, update_PQ
+//                                    :520-537, call_solver :213-275 = OSQP 0.6.x, retrieve_result :277-297)
+//
+// Mapping: lane = 4*instance_in_wave + foot, i.e. ONE QUAD PER ROBOT INSTANCE and 16 instances per
+// wavefront.  Each lane runs the kinematics / Newton-Euler recursion of its own leg; the base
+// wrench, the QP data and the 12-variable ADMM are shared inside the quad with DPP quad
+// permutes (no LDS).  The 20 friction-cone rows split 5 per lane and only touch that lane's 3
+// force variables, so A_qp x and A_qp' y are lane-local.
+//
+// Rigid-body formulation: classical Newton-Euler in base-frame coordinates (angular velocity /
+// acceleration, CoM accelerations, per-link force and moment), NOT the spatial-algebra recursion
+// the CPU oracle restates from Pinocchio — the two only share include/qrw_solo12_model.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/qrw_solo12_model.h"
+#include "qrw_device.h"
+#include "qrw_kernels.h"
+
+namespace qrw {
+
+namespace {
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+struct M3 {
+  V3 r0, r1, r2;  // rows
+};
+__device__ __forceinline__ V3 mul(const M3& m, V3 v) { return mk(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
+__device__ __forceinline__ V3 mulT(const M3& m, V3 v) {
+  return mk(m.r0.x * v.x + m.r1.x * v.y + m.r2.x * v.z, m.r0.y * v.x + m.r1.y * v.y + m.r2.y * v.z,
+            m.r0.z * v.x + m.r1.z * v.y + m.r2.z * v.z);
+}
+__device__ __forceinline__ V3 rotx(double c, double s, V3 v) { return mk(v.x, c * v.y - s * v.z, s * v.y + c * v.z); }
+__device__ __forceinline__ V3 roty(double c, double s, V3 v) { return mk(c * v.x + s * v.z, v.y, -s * v.x + c * v.z); }
+
+// Model constants of one leg (device copy of include/qrw_solo12_model.h)
+struct LegC {
+  V3 haa, hfe, kfe, foot;
+  double m[4];
+  V3 com[4];
+  double I[4][6];
+};
+__device__ __forceinline__ LegC leg_consts(int j) {
+  LegC L;
+  const double sx = (j < 2) ? 1.0 : -1.0, sy = (j & 1) ? -1.0 : 1.0;
+  // FL entries of QRW_SOLO12_MODEL with the mirror signs of QRW_LEG(sx, sy)
+  L.haa = mk(sx * 0.1946, sy * 0.0875, 0.0);
+  L.hfe = mk(0.0, sy * 0.014, 0.0);
+  L.kfe = mk(0.0, sy * 0.03745, -0.16);
+  L.foot = mk(0.0, sy * 0.008, -0.16);
+  L.m[0] = 0.14853845; L.m[1] = 0.14853845; L.m[2] = 0.03070001; L.m[3] = 0.00693606;
+  L.com[0] = mk(sx * -0.078707, sy * 0.01, 0.0);
+  L.com[1] = mk(0.00001377, sy * 0.01935853, -0.07870700);
+  L.com[2] = mk(0.0, sy * 0.00787644, -0.08928215);
+  L.com[3] = mk(0.0, 0.0, 0.00035767);
+  const double I0[6] = {0.00003024, sx * sy * 0.00004671, 0.0, 0.00041193, 0.0, 0.00041107};
+  const double I1[6] = {0.00041107, 0.0, 0.00000009, 0.00041193, sy * 0.00004671, 0.00003024};
+  const double I2[6] = {0.00012024, 0.0, 0.0, 0.00012029, sy * 0.00000305, 0.00000216};
+  const double I3[6] = {0.00000057, 0.0, 0.0, 0.00000084, 0.0, 0.00000053};
+#pragma unroll
+  for (int e = 0; e < 6; e++) { L.I[0][e] = I0[e]; L.I[1][e] = I1[e]; L.I[2][e] = I2[e]; L.I[3][e] = I3[e]; }
+  return L;
+}
+
+// inertia (about the CoM, link axes) applied in base coordinates: R I R' w
+__device__ __forceinline__ V3 inertia_apply(const double I[6], const M3& R, V3 w) {
+  const V3 wl = mulT(R, w);
+  const V3 hl = mk(I[0] * wl.x + I[1] * wl.y + I[2] * wl.z, I[1] * wl.x + I[3] * wl.y + I[4] * wl.z,
+                   I[2] * wl.x + I[4] * wl.y + I[5] * wl.z);
+  return mul(R, hl);
+}
+
+struct LegKin {
+  V3 p0, p1, p2, pf;  // joint origins and foot, base frame
+  V3 a0, a1;          // joint axes (a2 = a1)
+  M3 R0, R1, R2;      // link rotations (base <- link)
+  V3 J0, J1, J2;      // columns of the foot Jacobian (base frame)
+};
+
+__device__ __forceinline__ LegKin leg_kinematics(const LegC& C, const double q[3]) {
+  LegKin K;
+  const double c0 = cos(q[0]), s0 = sin(q[0]);
+  const double c1 = cos(q[1]), s1 = sin(q[1]);
+  const double c12 = cos(q[1] + q[2]), s12 = sin(q[1] + q[2]);
+  // R0 = Rx(q0); R1 = R0 Ry(q1); R2 = R0 Ry(q1 + q2)
+  K.R0.r0 = mk(1, 0, 0); K.R0.r1 = mk(0, c0, -s0); K.R0.r2 = mk(0, s0, c0);
+  K.R1.r0 = mk(c1, 0, s1); K.R1.r1 = mk(s0 * s1, c0, -s0 * c1); K.R1.r2 = mk(-c0 * s1, s0, c0 * c1);
+  K.R2.r0 = mk(c12, 0, s12); K.R2.r1 = mk(s0 * s12, c0, -s0 * c12); K.R2.r2 = mk(-c0 * s12, s0, c0 * c12);
+  K.p0 = C.haa;
+  K.p1 = K.p0 + mul(K.R0, C.hfe);
+  K.p2 = K.p1 + mul(K.R1, C.kfe);
+  K.pf = K.p2 + mul(K.R2, C.foot);
+  K.a0 = mk(1, 0, 0);
+  K.a1 = mk(0, c0, s0);
+  K.J0 = cross(K.a0, K.pf - K.p0);
+  K.J1 = cross(K.a1, K.pf - K.p1);
+  K.J2 = cross(K.a1, K.pf - K.p2);
+  return K;
+}
+
+// Newton-Euler for one leg hanging from a base that moves with (w_b, alpha_b) and whose origin has the
+// classical acceleration a_b (gravity already folded in). Returns the leg's contribution to the base
+// force / moment (about the base origin) and the three joint torques.
+__device__ __forceinline__ void leg_newton_euler(const LegC& C, const LegKin& K, const double dq[3], const double ddq[3],
+                                                 V3 wb, V3 alb, V3 ab, V3& Fsum, V3& Msum, double tau[3]) {
+  // angular velocity / acceleration of the three links
+  const V3 w0 = wb + dq[0] * K.a0;
+  const V3 al0 = alb + dq[0] * cross(wb, K.a0) + ddq[0] * K.a0;
+  const V3 w1 = w0 + dq[1] * K.a1;
+  const V3 al1 = al0 + dq[1] * cross(w0, K.a1) + ddq[1] * K.a1;
+  const V3 w2 = w1 + dq[2] * K.a1;
+  const V3 al2 = al1 + dq[2] * cross(w1, K.a1) + ddq[2] * K.a1;
+  // accelerations of the joint origins
+  const V3 ap0 = ab + cross(alb, K.p0) + cross(wb, cross(wb, K.p0));
+  const V3 d01 = K.p1 - K.p0, d12 = K.p2 - K.p1;
+  const V3 ap1 = ap0 + cross(al0, d01) + cross(w0, cross(w0, d01));
+  const V3 ap2 = ap1 + cross(al1, d12) + cross(w1, cross(w1, d12));
+  // bodies: shoulder (link 0), upper leg (link 1), lower leg and foot (both on link 2)
+  V3 F[4], Nn[4], c[4];
+  {
+    const V3 r = mul(K.R0, C.com[0]);
+    c[0] = K.p0 + r;
+    F[0] = C.m[0] * (ap0 + cross(al0, r) + cross(w0, cross(w0, r)));
+    Nn[0] = inertia_apply(C.I[0], K.R0, al0) + cross(w0, inertia_apply(C.I[0], K.R0, w0));
+  }
+  {
+    const V3 r = mul(K.R1, C.com[1]);
+    c[1] = K.p1 + r;
+    F[1] = C.m[1] * (ap1 + cross(al1, r) + cross(w1, cross(w1, r)));
+    Nn[1] = inertia_apply(C.I[1], K.R1, al1) + cross(w1, inertia_apply(C.I[1], K.R1, w1));
+  }
+  {
+    const V3 r = mul(K.R2, C.com[2]);
+    c[2] = K.p2 + r;
+    F[2] = C.m[2] * (ap2 + cross(al2, r) + cross(w2, cross(w2, r)));
+    Nn[2] = inertia_apply(C.I[2], K.R2, al2) + cross(w2, inertia_apply(C.I[2], K.R2, w2));
+  }
+  {
+    const V3 r = mul(K.R2, C.foot + C.com[3]);
+    c[3] = K.p2 + r;
+    F[3] = C.m[3] * (ap2 + cross(al2, r) + cross(w2, cross(w2, r)));
+    Nn[3] = inertia_apply(C.I[3], K.R2, al2) + cross(w2, inertia_apply(C.I[3], K.R2, w2));
+  }
+  // joint torques: axis . (moment of all outboard bodies about the joint origin)
+  V3 m2 = Nn[2] + cross(c[2] - K.p2, F[2]) + Nn[3] + cross(c[3] - K.p2, F[3]);
+  tau[2] = dot(K.a1, m2);
+  V3 m1 = Nn[1] + cross(c[1] - K.p1, F[1]) + Nn[2] + cross(c[2] - K.p1, F[2]) + Nn[3] + cross(c[3] - K.p1, F[3]);
+  tau[1] = dot(K.a1, m1);
+  V3 m0 = Nn[0] + cross(c[0] - K.p0, F[0]) + Nn[1] + cross(c[1] - K.p0, F[1]) + Nn[2] + cross(c[2] - K.p0, F[2]) +
+          Nn[3] + cross(c[3] - K.p0, F[3]);
+  tau[0] = dot(K.a0, m0);
+  Fsum = F[0] + F[1] + F[2] + F[3];
+  Msum = Nn[0] + cross(c[0], F[0]) + Nn[1] + cross(c[1], F[1]) + Nn[2] + cross(c[2], F[2]) + Nn[3] + cross(c[3], F[3]);
+}
+
+__device__ __forceinline__ V3 quad_sum3(V3 v) { return mk(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }
+
+__device__ __forceinline__ void inv3x3(V3 c0, V3 c1, V3 c2, M3& inv) {
+  // matrix with COLUMNS c0,c1,c2; cofactor inverse, rows returned
+  const double a = c0.x, b = c1.x, c = c2.x, d = c0.y, e = c1.y, f = c2.y, g = c0.z, h = c1.z, i = c2.z;
+  const double C00 = e * i - f * h, C10 = f * g - d * i, C20 = d * h - e * g;
+  const double id = 1.0 / (a * C00 + b * C10 + c * C20);
+  inv.r0 = mk(C00 * id, (c * h - b * i) * id, (b * f - c * e) * id);
+  inv.r1 = mk(C10 * id, (a * i - c * g) * id, (c * d - a * f) * id);
+  inv.r2 = mk(C20 * id, (b * g - a * h) * id, (a * e - b * d) * id);
+}
+
+// broadcast one lane's 3-vector to its quad, lane index compile-time
+template <int J>
+__device__ __forceinline__ void qb(const double in[3], double out[3]) {
+#pragma unroll
+  for (int t = 0; t < 3; t++) out[t] = quad_bcast<J>(in[t]);
+}
+
+// ------------------------------------------------------------------------------------------
+// 12-variable / 20-row box QP of QPWBC solved with OSQP-0.6-style ADMM inside one quad.
+//   min 1/2 x'Hx + g'x   s.t.  l <= G x <= u,  G block-diagonal (5x3 per foot), H rows 3j..3j+2 per lane
+// State (scaled iterates, rho, previous g) persists across calls exactly like the OSQP workspace.
+struct QpIo {
+  double Hrow[3][12];  // rows of H owned by this lane
+  double g[3];
+  double lo[5], up[5];
+};
+
+__device__ __forceinline__ void cone_rows(const double f[3], double mu, double out[5]) {
+  // G block of QPWBC.cpp:10-22: (-1,0,mu),(1,0,mu),(0,-1,mu),(0,1,mu),(0,0,1)
+  out[0] = -f[0] + mu * f[2];
+  out[1] = f[0] + mu * f[2];
+  out[2] = -f[1] + mu * f[2];
+  out[3] = f[1] + mu * f[2];
+  out[4] = f[2];
+}
+__device__ __forceinline__ void cone_rows_t(const double w[5], double mu, double out[3]) {
+  out[0] = -w[0] + w[1];
+  out[1] = -w[2] + w[3];
+  out[2] = mu * (w[0] + w[1] + w[2] + w[3]) + w[4];
+}
+
+__device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double sol[3], int& iter_out, int& status_out) {
+  const double mu = 0.9;  // QPWBC.hpp:30
+  const double sigma = 1e-6, alpha = 1.6;
+  const double eps_abs = (double)(float)1e-5, eps_rel = (double)(float)1e-5;  // QPWBC.cpp:239-240
+  const double eps_prim_inf = 1e-4, eps_dual_inf = 1e-4;
+  const bool first = !valid || !(st[kWsInit] != 0.0);  // padding quads always cold-start
+  double x[3], z[5], y[5], rho, gprev[3];
+  if (first) {
+    rho = 0.1;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { x[t] = 0.0; gprev[t] = io.g[t]; }
+#pragma unroll
+    for (int c = 0; c < 5; c++) z[c] = y[c] = 0.0;
+  } else {
+    rho = st[kWsRho];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { x[t] = st[kWsX + 3 * j + t]; gprev[t] = st[kWsG + 3 * j + t]; }
+#pragma unroll
+    for (int c = 0; c < 5; c++) { z[c] = st[kWsZ + 5 * j + c]; y[c] = st[kWsY + 5 * j + c]; }
+  }
+  // ---- scale_data: on setup q is the current g; inside osqp_update_P it is still the PREVIOUS call's g
+  // (osqp_update_lin_cost runs afterwards, QPWBC.cpp:258-261)
+  double D[3] = {1, 1, 1}, E[5] = {1, 1, 1, 1, 1}, cs = 1.0;
+  const double Gabs[5][3] = {{1, 0, mu}, {1, 0, mu}, {0, 1, mu}, {0, 1, mu}, {0, 0, 1}};
+  for (int pass = 0; pass < 10; pass++) {
+    double Dall[12];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      Dall[t] = quad_bcast<0>(D[t]); Dall[3 + t] = quad_bcast<1>(D[t]);
+      Dall[6 + t] = quad_bcast<2>(D[t]); Dall[9 + t] = quad_bcast<3>(D[t]);
+    }
+    double nD[3], nE[5];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      double v = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) v = fmax(v, fabs(cs * D[t] * io.Hrow[t][cb] * Dall[cb]));
+#pragma unroll
+      for (int c = 0; c < 5; c++) v = fmax(v, E[c] * Gabs[c][t] * D[t]);
+      nD[t] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      double v = 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) v = fmax(v, E[c] * Gabs[c][t] * D[t]);
+      nE[c] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) D[t] *= 1.0 / sqrt(limit_scaling(nD[t]));
+#pragma unroll
+    for (int c = 0; c < 5; c++) E[c] *= 1.0 / sqrt(limit_scaling(nE[c]));
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      Dall[t] = quad_bcast<0>(D[t]); Dall[3 + t] = quad_bcast<1>(D[t]);
+      Dall[6 + t] = quad_bcast<2>(D[t]); Dall[9 + t] = quad_bcast<3>(D[t]);
+    }
+    double colsum = 0.0, qn = 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      double v = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) v = fmax(v, fabs(cs * D[t] * io.Hrow[t][cb] * Dall[cb]));
+      colsum += v;
+      qn = fmax(qn, fabs(cs * D[t] * gprev[t]));
+    }
+    double ct = quad_sum(colsum) * (1.0 / 12.0);
+    qn = limit_scaling(quad_max(qn));
+    ct = fmax(ct, qn);
+    ct = limit_scaling(ct);
+    cs *= 1.0 / ct;
+  }
+  const double cinv = 1.0 / cs;
+  double iD[3], iE[5], ls[5], us[5];
+#pragma unroll
+  for (int t = 0; t < 3; t++) iD[t] = 1.0 / D[t];
+#pragma unroll
+  for (int c = 0; c < 5; c++) { iE[c] = 1.0 / E[c]; ls[c] = E[c] * io.lo[c]; us[c] = E[c] * io.up[c]; }
+  rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+
+  double Ki[3][12];
+  bool need_factor = true;
+  int iter, status = kStatusUnsolved;
+  double last_np = 0.0, last_nd = 0.0, pri_res = 0.0, dua_res = 0.0;
+  const int max_iter = 4000;
+  for (iter = 1; iter <= max_iter; iter++) {
+    if (need_factor) {  // Khat = c H + sigma D^-2 + rho G' E^2 G, inverted by Gauss-Jordan inside the quad
+      need_factor = false;
+      double om[5];
+#pragma unroll
+      for (int c = 0; c < 5; c++) om[c] = rho * E[c] * E[c];
+      const double s4 = om[0] + om[1] + om[2] + om[3];
+      const double cone[3][3] = {{om[0] + om[1], 0.0, mu * (om[1] - om[0])},
+                                 {0.0, om[2] + om[3], mu * (om[3] - om[2])},
+                                 {mu * (om[1] - om[0]), mu * (om[3] - om[2]), mu * mu * s4 + om[4]}};
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int cb = 0; cb < 12; cb++) {
+          double v = cs * io.Hrow[t][cb];
+          if (cb / 3 == j) {
+            v += cone[t][cb % 3];
+            if (cb % 3 == t) v += sigma * iD[t] * iD[t];
+          }
+          Ki[t][cb] = valid ? v : ((cb / 3 == j && cb % 3 == t) ? 1.0 : 0.0);
+        }
+#pragma unroll
+      for (int p = 0; p < 12; p++) {
+        const int jp = p / 3, tp = p % 3;
+        double prow[12];
+#pragma unroll
+        for (int cb = 0; cb < 12; cb++) {
+          const double src = Ki[tp][cb];
+          prow[cb] = (jp == 0) ? quad_bcast<0>(src) : (jp == 1) ? quad_bcast<1>(src) : (jp == 2) ? quad_bcast<2>(src) : quad_bcast<3>(src);
+        }
+        const double d = 1.0 / prow[p];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const bool isp = (j == jp) && (t == tp);
+          const double fcol = Ki[t][p];
+#pragma unroll
+          for (int cb = 0; cb < 12; cb++) {
+            double v;
+            if (cb == p) v = isp ? d : -fcol * d;
+            else v = isp ? prow[cb] * d : Ki[t][cb] - fcol * prow[cb] * d;
+            Ki[t][cb] = v;
+          }
+        }
+      }
+    }
+    const double rho_inv = 1.0 / rho;
+    // rhs (hatted): sigma x / D - c g + G' E (rho z - y)
+    double w[5], gt[3], r[3], rall[12];
+#pragma unroll
+    for (int c = 0; c < 5; c++) w[c] = E[c] * (rho * (z[c] - rho_inv * y[c]));
+    cone_rows_t(w, mu, gt);
+#pragma unroll
+    for (int t = 0; t < 3; t++) r[t] = sigma * x[t] * iD[t] - cs * io.g[t] + gt[t];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      rall[t] = quad_bcast<0>(r[t]); rall[3 + t] = quad_bcast<1>(r[t]);
+      rall[6 + t] = quad_bcast<2>(r[t]); rall[9 + t] = quad_bcast<3>(r[t]);
+    }
+    double xh[3], zt[5], cv[5], dx[3], dy[5];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      double v = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) v += Ki[t][cb] * rall[cb];
+      xh[t] = v;
+    }
+    cone_rows(xh, mu, cv);
+#pragma unroll
+    for (int c = 0; c < 5; c++) zt[c] = E[c] * cv[c];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const double xn = alpha * (xh[t] * iD[t]) + (1.0 - alpha) * x[t];
+      dx[t] = xn - x[t];
+      x[t] = xn;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      const double zr = alpha * zt[c] + (1.0 - alpha) * z[c];
+      double zn = zr + rho_inv * y[c];
+      zn = fmin(fmax(zn, ls[c]), us[c]);
+      dy[c] = rho * (zr - zn);
+      y[c] += dy[c];
+      z[c] = zn;
+    }
+    if (iter % 25 == 0) {
+      double xs[3], xall[12];
+#pragma unroll
+      for (int t = 0; t < 3; t++) xs[t] = D[t] * x[t];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        xall[t] = quad_bcast<0>(xs[t]); xall[3 + t] = quad_bcast<1>(xs[t]);
+        xall[6 + t] = quad_bcast<2>(xs[t]); xall[9 + t] = quad_bcast<3>(xs[t]);
+      }
+      double pres = 0, nz = 0, nax = 0, pres_s = 0, nz_s = 0, nax_s = 0;
+      cone_rows(xs, mu, cv);
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        const double axs = E[c] * cv[c], rs = axs - z[c];
+        pres_s = fmax(pres_s, fabs(rs)); nz_s = fmax(nz_s, fabs(z[c])); nax_s = fmax(nax_s, fabs(axs));
+        pres = fmax(pres, fabs(iE[c] * rs)); nz = fmax(nz, fabs(iE[c] * z[c])); nax = fmax(nax, fabs(iE[c] * axs));
+      }
+      double ey[5], aty[3];
+#pragma unroll
+      for (int c = 0; c < 5; c++) ey[c] = E[c] * y[c];
+      cone_rows_t(ey, mu, aty);
+      double dres = 0, naty = 0, npx = 0, nq = 0, dres_s = 0, naty_s = 0, npx_s = 0, nq_s = 0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        double px = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < 12; cb++) px += io.Hrow[t][cb] * xall[cb];
+        px *= cs;
+        const double qh = cs * io.g[t];
+        dres = fmax(dres, fabs(px + qh + aty[t])); naty = fmax(naty, fabs(aty[t])); npx = fmax(npx, fabs(px));
+        nq = fmax(nq, fabs(qh));
+        dres_s = fmax(dres_s, fabs(D[t] * (px + qh + aty[t]))); naty_s = fmax(naty_s, fabs(D[t] * aty[t]));
+        npx_s = fmax(npx_s, fabs(D[t] * px)); nq_s = fmax(nq_s, fabs(D[t] * qh));
+      }
+      pres = quad_max(pres); nz = quad_max(nz); nax = quad_max(nax);
+      dres = quad_max(dres); naty = quad_max(naty); npx = quad_max(npx); nq = quad_max(nq);
+      pri_res = pres;
+      dua_res = cinv * dres;
+      last_np = fmax(nz, nax);
+      last_nd = cinv * fmax(fmax(naty, npx), nq);
+      bool done = false;
+      if (pri_res > kOsqpInfty || dua_res > kOsqpInfty) {
+        status = kStatusNonCvx;
+        done = true;
+      } else {
+        const bool pok = pri_res < eps_abs + eps_rel * last_np;
+        const bool dok = dua_res < eps_abs + eps_rel * last_nd;
+        bool pinf = false, dinf = false;
+        if (!pok) {  // is_primal_infeasible: all bounds finite here, so delta_y is not projected
+          double ndy = 0.0, lhs = 0.0;
+#pragma unroll
+          for (int c = 0; c < 5; c++) {
+            ndy = fmax(ndy, fabs(E[c] * dy[c]));
+            lhs += us[c] * fmax(dy[c], 0.0) + ls[c] * fmin(dy[c], 0.0);
+          }
+          ndy = quad_max(ndy);
+          lhs = quad_sum(lhs);
+          if (ndy > eps_prim_inf && lhs < -eps_prim_inf * ndy) {
+            double at[3], na = 0.0, edy[5];  // Dinv A_s' dy = G' (E dy)
+#pragma unroll
+            for (int c = 0; c < 5; c++) edy[c] = E[c] * dy[c];
+            cone_rows_t(edy, mu, at);
+#pragma unroll
+            for (int t = 0; t < 3; t++) na = fmax(na, fabs(at[t]));
+            na = quad_max(na);
+            pinf = na < eps_prim_inf * ndy;
+          }
+        }
+        if (!dok) {  // is_dual_infeasible
+          double ndx = 0.0, qdx = 0.0;
+#pragma unroll
+          for (int t = 0; t < 3; t++) {
+            ndx = fmax(ndx, fabs(D[t] * dx[t]));
+            qdx += (cs * D[t] * io.g[t]) * dx[t];
+          }
+          ndx = quad_max(ndx);
+          qdx = quad_sum(qdx);
+          if (ndx > eps_dual_inf && qdx < -cs * eps_dual_inf * ndx) {
+            double dxs[3], dall[12], npd = 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; t++) dxs[t] = D[t] * dx[t];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+              dall[t] = quad_bcast<0>(dxs[t]); dall[3 + t] = quad_bcast<1>(dxs[t]);
+              dall[6 + t] = quad_bcast<2>(dxs[t]); dall[9 + t] = quad_bcast<3>(dxs[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+              double v = 0.0;
+#pragma unroll
+              for (int cb = 0; cb < 12; cb++) v += io.Hrow[t][cb] * dall[cb];
+              npd = fmax(npd, fabs(cs * v));
+            }
+            npd = quad_max(npd);
+            if (npd < cs * eps_dual_inf * ndx) {
+              double adx[5];
+              bool ok = true;
+              cone_rows(dxs, mu, adx);  // Einv A_s dx = G (D dx)
+#pragma unroll
+              for (int c = 0; c < 5; c++)
+                if (adx[c] > eps_dual_inf * ndx || adx[c] < -eps_dual_inf * ndx) ok = false;
+              const unsigned long long bl = __ballot(!ok);
+              const int base = (threadIdx.x & 63) & ~3;
+              dinf = ((bl >> base) & 0xFull) == 0;
+            }
+          }
+        }
+        if (pok && dok) { status = kStatusSolved; done = true; }
+        else if (pinf) { status = kStatusPrimalInf; done = true; }
+        else if (dinf) { status = kStatusDualInf; done = true; }
+      }
+      if (done) break;
+      if (iter % 200 == 0) {
+        pres_s = quad_max(pres_s); nz_s = quad_max(nz_s); nax_s = quad_max(nax_s);
+        dres_s = quad_max(dres_s); naty_s = quad_max(naty_s); npx_s = quad_max(npx_s); nq_s = quad_max(nq_s);
+        const double pn = pres_s / (fmax(nz_s, nax_s) + 1e-10);
+        const double dn = dres_s / (fmax(fmax(naty_s, npx_s), nq_s) + 1e-10);
+        double rho_new = rho * sqrt(pn / (dn + 1e-10));
+        rho_new = fmin(fmax(rho_new, kRhoMin), kRhoMax);
+        if (rho_new > rho * 5.0 || rho_new < rho / 5.0) {
+          rho = rho_new;
+          need_factor = true;
+        }
+      }
+    }
+  }
+  if (iter > max_iter) iter = max_iter;
+  if (status == kStatusUnsolved) {
+    const bool pok = pri_res < 10 * eps_abs + 10 * eps_rel * last_np;
+    const bool dok = dua_res < 10 * eps_abs + 10 * eps_rel * last_nd;
+    status = (pok && dok) ? kStatusSolvedInaccurate : kStatusMaxIter;
+  }
+  const bool has_sol = (status == kStatusSolved || status == kStatusSolvedInaccurate || status == kStatusMaxIter);
+#pragma unroll
+  for (int t = 0; t < 3; t++) sol[t] = has_sol ? D[t] * x[t] : nan("");
+  if (!has_sol) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) x[t] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) z[c] = y[c] = 0.0;
+  }
+  if (valid) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) { st[kWsX + 3 * j + t] = x[t]; st[kWsG + 3 * j + t] = io.g[t]; }
+#pragma unroll
+    for (int c = 0; c < 5; c++) { st[kWsZ + 5 * j + c] = z[c]; st[kWsY + 5 * j + c] = y[c]; }
+    if (j == 0) { st[kWsRho] = rho; st[kWsInit] = 1.0; }
+  }
+  iter_out = iter;
+  status_out = status;
+}
+
+// QP data from per-foot A blocks (6x3), gamma and f_cmd (QPWBC::compute_matrices + update_PQ + bounds)
+__device__ __forceinline__ void qp_build(const double Aj[6][3], const double gamma[6], const double fc[3], int j,
+                                         QpIo& io) {
+  const double mu = 0.9;
+  double Aall[6][12];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      Aall[i][t] = quad_bcast<0>(Aj[i][t]); Aall[i][3 + t] = quad_bcast<1>(Aj[i][t]);
+      Aall[i][6 + t] = quad_bcast<2>(Aj[i][t]); Aall[i][9 + t] = quad_bcast<3>(Aj[i][t]);
+    }
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+#pragma unroll
+    for (int cb = 0; cb < 12; cb++) {
+      double v = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) v += (Aj[i][t] * 0.1) * Aall[i][cb];
+      if (cb / 3 == j && cb % 3 == t) v += 5.0;
+      io.Hrow[t][cb] = v;
+    }
+    double gv = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gv += (Aj[i][t] * 0.1) * gamma[i];
+    io.g[t] = gv;
+  }
+  double gf[5];
+  cone_rows(fc, mu, gf);
+#pragma unroll
+  for (int c = 0; c < 5; c++) { io.lo[c] = -gf[c]; io.up[c] = -gf[c] + 25.0; }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
+  const int lane = threadIdx.x;
+  const int j = lane & 3;
+  const int b = blockIdx.x * 16 + (lane >> 2);
+  const bool valid = b < a.B;
+  const int bb = valid ? b : 0;
+  const LegC C = leg_consts(j);
+  double* st = a.st + (size_t)bb * kWbcStItems;
+
+  if (a.mode == 1) {  // fixed-base feet kinematics only (qrw_fixed_feet_host)
+    double q[3], dq[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { q[t] = a.in0[bb * 12 + 3 * j + t]; dq[t] = a.in1[bb * 12 + 3 * j + t]; }
+    const LegKin K = leg_kinematics(C, q);
+    const V3 vf = dq[0] * K.J0 + dq[1] * K.J1 + dq[2] * K.J2;
+    const V3 w0 = dq[0] * K.a0, w1 = w0 + dq[1] * K.a1, w2 = w1 + dq[2] * K.a1;
+    const V3 da1 = dq[0] * cross(K.a0, K.a1);
+    const V3 vp1 = cross(w0, K.p1 - K.p0), vp2 = vp1 + cross(w1, K.p2 - K.p1);
+    const V3 acl = dq[0] * cross(K.a0, vf) + dq[1] * (cross(da1, K.pf - K.p1) + cross(K.a1, vf - vp1)) +
+                   dq[2] * (cross(da1, K.pf - K.p2) + cross(K.a1, vf - vp2));
+    const V3 af = acl - cross(w2, vf);
+    if (valid) {
+      double* o;
+      o = a.out0 + bb * 12 + 3 * j; o[0] = K.pf.x; o[1] = K.pf.y; o[2] = K.pf.z;
+      o = a.out1 + bb * 12 + 3 * j; o[0] = vf.x; o[1] = vf.y; o[2] = vf.z;
+      o = a.out2 + bb * 12 + 3 * j; o[0] = w2.x; o[1] = w2.y; o[2] = w2.z;
+      o = a.out3 + bb * 12 + 3 * j; o[0] = af.x; o[1] = af.y; o[2] = af.z;
+      double* J = a.out4 + bb * 144;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 12; c++) J[(3 * j + r) * 12 + c] = 0.0;
+      J[(3 * j + 0) * 12 + 3 * j + 0] = K.J0.x; J[(3 * j + 1) * 12 + 3 * j + 0] = K.J0.y; J[(3 * j + 2) * 12 + 3 * j + 0] = K.J0.z;
+      J[(3 * j + 0) * 12 + 3 * j + 1] = K.J1.x; J[(3 * j + 1) * 12 + 3 * j + 1] = K.J1.y; J[(3 * j + 2) * 12 + 3 * j + 1] = K.J1.z;
+      J[(3 * j + 0) * 12 + 3 * j + 2] = K.J2.x; J[(3 * j + 1) * 12 + 3 * j + 2] = K.J2.y; J[(3 * j + 2) * 12 + 3 * j + 2] = K.J2.z;
+    }
+    return;
+  }
+  if (a.mode == 2) {  // InvKin::refreshAndCompute from caller-supplied kinematics (qrw_invkin_host)
+    const double ct = a.in0[bb * 4 + j];
+    V3 goal = mk(a.in1[bb * 12 + 0 * 4 + j], a.in1[bb * 12 + 1 * 4 + j], a.in1[bb * 12 + 2 * 4 + j]);
+    V3 vg = mk(a.in2[bb * 12 + 0 * 4 + j], a.in2[bb * 12 + 1 * 4 + j], a.in2[bb * 12 + 2 * 4 + j]);
+    V3 ag = mk(a.in3[bb * 12 + 0 * 4 + j], a.in3[bb * 12 + 1 * 4 + j], a.in3[bb * 12 + 2 * 4 + j]);
+    const double* pp = a.in4 + bb * 12 + 3 * j; V3 pos = mk(pp[0], pp[1], pp[2]);
+    pp = a.in5 + bb * 12 + 3 * j; V3 vf = mk(pp[0], pp[1], pp[2]);
+    pp = a.in6 + bb * 12 + 3 * j; V3 wf = mk(pp[0], pp[1], pp[2]);
+    pp = a.in7 + bb * 12 + 3 * j; V3 af = mk(pp[0], pp[1], pp[2]);
+    const double* Jf = a.in8 + bb * 144 + (3 * j) * 12 + 3 * j;
+    M3 iJ;
+    inv3x3(mk(Jf[0], Jf[12], Jf[24]), mk(Jf[1], Jf[13], Jf[25]), mk(Jf[2], Jf[14], Jf[26]), iJ);
+    const V3 e = goal - pos;
+    V3 acc = 100.0 * e - (2.0 * sqrt(100.0)) * (vf - vg) + ag;
+    if (ct != 0.0) acc = 0.0 * acc;
+    acc = acc - (af + cross(wf, vf));
+    const V3 ddq = mul(iJ, acc), dqc = mul(iJ, vg), qs = mul(iJ, e);
+    if (valid) {
+      double* o;
+      o = a.out0 + bb * 12 + 3 * j; o[0] = ddq.x; o[1] = ddq.y; o[2] = ddq.z;
+      o = a.out1 + bb * 12 + 3 * j; o[0] = dqc.x; o[1] = dqc.y; o[2] = dqc.z;
+      o = a.out2 + bb * 12 + 3 * j; o[0] = qs.x; o[1] = qs.y; o[2] = qs.z;
+    }
+    return;
+  }
+  if (a.mode == 3) {  // QPWBC::run from caller-supplied M (diagonal), Jc, f_cmd, RNEA (qrw_qpwbc_host)
+    const double* M = a.in0 + (size_t)bb * 324;
+    const double* Jc = a.in1 + (size_t)bb * 216;
+    double Yd[6], Yi[6], smax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { Yd[i] = M[i * 18 + i]; smax = fmax(smax, fabs(Yd[i])); }
+    const double tol = 2.220446049250313e-16 * 6.0 * smax;  // pseudoInverse<>, InvKin.hpp:60-66
+#pragma unroll
+    for (int i = 0; i < 6; i++) Yi[i] = (fabs(Yd[i]) > tol) ? 1.0 / Yd[i] : 0.0;
+    double Aj[6][3], fc[3], xf[6], gamma[6];
+#pragma unroll
+    for (int t = 0; t < 3; t++) fc[t] = a.in2[bb * 12 + 3 * j + t];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const double xv = Jc[(3 * j + t) * 18 + i];
+        Aj[i][t] = Yi[i] * xv;
+        s_ += xv * fc[t];
+      }
+      xf[i] = quad_sum(s_);
+      gamma[i] = Yi[i] * (xf[i] - a.in3[bb * 6 + i]);
+    }
+    QpIo io;
+    qp_build(Aj, gamma, fc, j, io);
+    double sol[3];
+    int it, stt;
+    qp_solve(io, st, j, valid, sol, it, stt);
+    double dd[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dd[i] = quad_sum(Aj[i][0] * sol[0] + Aj[i][1] * sol[1] + Aj[i][2] * sol[2]) + gamma[i];
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 3; t++) a.out0[bb * 12 + 3 * j + t] = sol[t] + fc[t];
+      if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.out1[bb * 6 + i] = dd[i];
+        a.iters[bb] = it;
+        a.status[bb] = stt;
+      }
+      if (a.out2) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+          for (int cb = 0; cb < 12; cb++) a.out2[(size_t)bb * 144 + (3 * j + t) * 12 + cb] = io.Hrow[t][cb];
+      }
+    }
+    return;
+  }
+
+  // ================================ full wbc_controller.compute ================================
+  const double* qv = a.q + (size_t)bb * 19;
+  const double* dqv = a.dq + (size_t)bb * 18;
+  double q[3], dq[3], fc[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) { q[t] = qv[7 + 3 * j + t]; dq[t] = dqv[6 + 3 * j + t]; fc[t] = a.f_cmd[bb * 12 + 3 * j + t]; }
+  const double contact = a.contacts[bb * 4 + j];
+  const bool stance = (contact != 0.0);
+  {  // k_since_contact (QP_WBC.py:65-66)
+    double ks = st[kWsKsc + j];
+    ks += contact;
+    ks *= contact;
+    if (valid) st[kWsKsc + j] = ks;
+  }
+  const LegKin K = leg_kinematics(C, q);
+  // ---- fixed-base foot velocity and classical acceleration with zero joint acceleration
+  const V3 vf = dq[0] * K.J0 + dq[1] * K.J1 + dq[2] * K.J2;
+  V3 acl;
+  {
+    const V3 w0 = dq[0] * K.a0, w1 = w0 + dq[1] * K.a1;
+    const V3 da1 = dq[0] * cross(K.a0, K.a1);
+    const V3 vp1 = cross(w0, K.p1 - K.p0), vp2 = vp1 + cross(w1, K.p2 - K.p1);
+    acl = dq[0] * cross(K.a0, vf) + dq[1] * (cross(da1, K.pf - K.p1) + cross(K.a1, vf - vp1)) +
+          dq[2] * (cross(da1, K.pf - K.p2) + cross(K.a1, vf - vp2));
+  }
+  // ---- InvKin (src/InvKin.cpp:36-62); af + w x v of the reference IS the classical acceleration
+  const V3 goal = mk(a.pgoals[bb * 12 + 0 * 4 + j], a.pgoals[bb * 12 + 1 * 4 + j], a.pgoals[bb * 12 + 2 * 4 + j]);
+  const V3 vgoal = mk(a.vgoals[bb * 12 + 0 * 4 + j], a.vgoals[bb * 12 + 1 * 4 + j], a.vgoals[bb * 12 + 2 * 4 + j]);
+  const V3 agoal = mk(a.agoals[bb * 12 + 0 * 4 + j], a.agoals[bb * 12 + 1 * 4 + j], a.agoals[bb * 12 + 2 * 4 + j]);
+  M3 iJ;
+  inv3x3(K.J0, K.J1, K.J2, iJ);
+  const V3 perr = goal - K.pf;
+  V3 afeet = 100.0 * perr - (2.0 * sqrt(100.0)) * (vf - vgoal) + agoal;
+  if (stance) afeet = 0.0 * afeet;
+  afeet = afeet - acl;
+  const V3 ddq3 = mul(iJ, afeet), dqc3 = mul(iJ, vgoal), qs3 = mul(iJ, perr);
+  const double ddq[3] = {ddq3.x, ddq3.y, ddq3.z};
+
+  // ---- free-flyer quantities
+  M3 Rb;
+  {
+    const double x = qv[3], y = qv[4], z = qv[5], w = qv[6];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                 tyz = tz * y, tzz = tz * z;
+    Rb.r0 = mk(1 - (tyy + tzz), txy - twz, txz + twy);
+    Rb.r1 = mk(txy + twz, 1 - (txx + tzz), tyz - twx);
+    Rb.r2 = mk(txz - twy, tyz + twx, 1 - (txx + tyy));
+  }
+  const V3 vb = mk(dqv[0], dqv[1], dqv[2]), wb = mk(dqv[3], dqv[4], dqv[5]);
+  const V3 grav = mulT(Rb, mk(0.0, 0.0, QRW_SOLO12_MODEL.gravity));  // -gravity in base coordinates
+  const V3 ab0 = grav + cross(wb, vb);                               // classical base accel, ddq_base = 0
+  const qrw_link_inertial& BL = QRW_SOLO12_MODEL.base;
+  const double Ib[6] = {BL.inertia[0], BL.inertia[1], BL.inertia[2], BL.inertia[3], BL.inertia[4], BL.inertia[5]};
+  const V3 cb = mk(BL.com[0], BL.com[1], BL.com[2]);
+  M3 Id;
+  Id.r0 = mk(1, 0, 0); Id.r1 = mk(0, 1, 0); Id.r2 = mk(0, 0, 1);
+  // first rnea: base acceleration 0, joint acceleration ddq_cmd (QP_WBC.py:104); only [:6] is used
+  V3 Fl, Ml;
+  double tau1[3];
+  leg_newton_euler(C, K, dq, ddq, wb, mk(0, 0, 0), ab0, Fl, Ml, tau1);
+  V3 Fb = BL.mass * (ab0 + cross(wb, cross(wb, cb)));
+  V3 Mb = inertia_apply(Ib, Id, mk(0, 0, 0)) + cross(wb, inertia_apply(Ib, Id, wb)) + cross(cb, Fb);
+  const V3 F6 = quad_sum3(Fl) + Fb, M6 = quad_sum3(Ml) + Mb;
+  const double rnea6[6] = {F6.x, F6.y, F6.z, M6.x, M6.y, M6.z};
+  // ---- QP data: X = Jc[:, :6]', A = Yinv X (QPWBC.cpp:491-497)
+  double Aj[6][3], gamma[6];
+  {
+    // rows of Jc for this foot: [Rb, -Rb skew(r)] -> X block = [Rb'; skew(r) Rb'] (6x3), zero in swing
+    const V3 r = K.pf;
+    const V3 c0 = mk(Rb.r0.x, Rb.r1.x, Rb.r2.x), c1 = mk(Rb.r0.y, Rb.r1.y, Rb.r2.y), c2 = mk(Rb.r0.z, Rb.r1.z, Rb.r2.z);
+    // Rb' has rows c0,c1,c2 (columns of Rb); column t of Rb' is row t of Rb
+    const V3 rt[3] = {Rb.r0, Rb.r1, Rb.r2};
+    double X[6][3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const V3 col = mk(rt[t].x, rt[t].y, rt[t].z);  // Rb'(:,t) = (Rb(t,0), Rb(t,1), Rb(t,2))
+      const V3 sc = cross(r, col);
+      X[0][t] = col.x; X[1][t] = col.y; X[2][t] = col.z;
+      X[3][t] = sc.x; X[4][t] = sc.y; X[5][t] = sc.z;
+    }
+    (void)c0; (void)c1; (void)c2;
+    double xf[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const double xv = stance ? X[i][t] : 0.0;
+        Aj[i][t] = (1.0 / a.Y[i]) * xv;
+        s_ += xv * fc[t];
+      }
+      xf[i] = quad_sum(s_);
+      gamma[i] = (1.0 / a.Y[i]) * (xf[i] - rnea6[i]);
+    }
+  }
+  QpIo io;
+  qp_build(Aj, gamma, fc, j, io);
+  double sol[3];
+  int it, stt;
+  qp_solve(io, st, j, valid, sol, it, stt);
+  double dd[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) dd[i] = quad_sum(Aj[i][0] * sol[0] + Aj[i][1] * sol[1] + Aj[i][2] * sol[2]) + gamma[i];
+  const double fw[3] = {sol[0] + fc[0], sol[1] + fc[1], sol[2] + fc[2]};
+  // second rnea with the base acceleration found by the QP (QP_WBC.py:110-116); only [6:] is used
+  const V3 alb = mk(dd[3], dd[4], dd[5]);
+  const V3 ab1 = ab0 + mk(dd[0], dd[1], dd[2]);
+  double tau2[3];
+  leg_newton_euler(C, K, dq, ddq, wb, alb, ab1, Fl, Ml, tau2);
+  // tau_ff = RNEA_delta - Jc[:, 6:]' f (QP_WBC.py:117): Jc joint block of a stance foot = Rb J_leg
+  double tff[3];
+  {
+    const V3 fbv = mulT(Rb, mk(fw[0], fw[1], fw[2]));  // Rb' f
+    tff[0] = tau2[0] - (stance ? dot(K.J0, fbv) : 0.0);
+    tff[1] = tau2[1] - (stance ? dot(K.J1, fbv) : 0.0);
+    tff[2] = tau2[2] - (stance ? dot(K.J2, fbv) : 0.0);
+  }
+  if (valid) {
+    if (a.tau_ff) { double* o = a.tau_ff + bb * 12 + 3 * j; o[0] = tff[0]; o[1] = tff[1]; o[2] = tff[2]; }
+    if (a.qdes) {
+      double* o = a.qdes + bb * 19;
+      if (j == 0) for (int i = 0; i < 7; i++) o[i] = 0.0;  // q_cmd[:7] is never written (solo12InvKin.py:67)
+      o[7 + 3 * j] = q[0] + qs3.x; o[8 + 3 * j] = q[1] + qs3.y; o[9 + 3 * j] = q[2] + qs3.z;
+    }
+    if (a.vdes) {
+      double* o = a.vdes + bb * 18;
+      if (j == 0) for (int i = 0; i < 6; i++) o[i] = 0.0;
+      o[6 + 3 * j] = dqc3.x; o[7 + 3 * j] = dqc3.y; o[8 + 3 * j] = dqc3.z;
+    }
+    if (a.f_with_delta) { double* o = a.f_with_delta + bb * 12 + 3 * j; o[0] = fw[0]; o[1] = fw[1]; o[2] = fw[2]; }
+    if (a.ddq_res && j == 0)
+      for (int i = 0; i < 6; i++) a.ddq_res[bb * 6 + i] = dd[i];
+    if (a.feet) {  // feet_pos, feet_err, feet_vel as 3x4 each (QP_WBC.py:73-80)
+      double* o = a.feet + (size_t)bb * 36;
+      o[0 * 4 + j] = K.pf.x; o[1 * 4 + j] = K.pf.y; o[2 * 4 + j] = K.pf.z;
+      o[12 + 0 * 4 + j] = perr.x; o[12 + 1 * 4 + j] = perr.y; o[12 + 2 * 4 + j] = perr.z;
+      o[24 + 0 * 4 + j] = vf.x; o[24 + 1 * 4 + j] = vf.y; o[24 + 2 * 4 + j] = vf.z;
+    }
+    if (j == 0) { a.iters[bb] = it; a.status[bb] = stt; }
+  }
+}
+
+int wbc_launch(const WbcArgs& a, hipStream_t stream) {
+  const int blocks = (a.B + 15) / 16;
+  hipLaunchKernelGGL(wbc_kernel, dim3(blocks), dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace qrw

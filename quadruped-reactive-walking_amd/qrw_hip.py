@@ -1,0 +1,265 @@
+"""ctypes binding of libqrw_hip.so (C ABI: include/qrw_hip.h) — the only way Python reaches the kernels.
+
+Replaces the Boost.Python/eigenpy module of the reference (python/gepadd.cpp). The library is
+gfx950-only and has NO CPU fallback: loading works anywhere (so symbols can be checked without a
+GPU), but creating a handle without a HIP device raises.
+
+`Batch` is the batched, device-resident API (torch tensors in, torch tensors out, caller's
+stream); the *_host methods take/return numpy arrays and are what the single-robot drop-in
+classes (libquadruped_reactive_walking.py) use.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libqrw_hip.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class QrwError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n_steps", C.c_int32), ("N_gait", C.c_int32), ("device", C.c_int32),
+                ("dt_mpc", C.c_double), ("T_gait", C.c_double), ("dt_wbc", C.c_double)]
+
+
+# every symbol include/qrw_hip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "qrw_create": (C.c_int, [C.POINTER(_Config), C.POINTER(_vp)]),
+    "qrw_destroy": (C.c_int, [_vp]),
+    "qrw_last_error": (C.c_char_p, []),
+    "qrw_mpc_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    "qrw_mpc_solve_host": (C.c_int, [_vp, _dp, _dp, _ip, C.c_int32, _dp]),
+    "qrw_mpc_get_gait": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
+    "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
+    "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),
+    "qrw_wbc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "qrw_invkin_host": (C.c_int, [_vp] + [_dp] * 12),
+    "qrw_qpwbc_host": (C.c_int, [_vp] + [_dp] * 7),
+    "qrw_fixed_feet_host": (C.c_int, [_vp] + [_dp] * 7),
+    "qrw_get_base_inertia_diag": (C.c_int, [_vp, _dp]),
+    "qrw_selftest_mfma": (C.c_int, [_dp]),
+    "qrw_state_bytes": (C.c_int64, [_vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libqrw_hip.so and attach the signatures. Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise QrwError("libqrw_hip.so is not built (run `make -C quadruped-reactive-walking_amd/csrc` or "
+                       "__graft_entry__.build()); there is no CPU fallback")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the host API
+        pass
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().qrw_last_error()
+        raise QrwError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _h(a, shape):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if a.shape != tuple(shape):
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def selftest_mfma():
+    err = C.c_double(0.0)
+    rc = load_library().qrw_selftest_mfma(C.byref(err))
+    return rc, err.value
+
+
+class Batch:
+    """B robot instances resident on one GPU: persistent MPC / WBC solver state + kernels."""
+
+    def __init__(self, batch, n_steps=16, N_gait=20, dt_mpc=0.02, T_gait=0.32, dt_wbc=0.002, device=0):
+        self._lib = load_library()
+        self.B, self.N, self.N_gait = int(batch), int(n_steps), int(N_gait)
+        self.dt_mpc, self.dt_wbc, self.T_gait, self.device = float(dt_mpc), float(dt_wbc), float(T_gait), int(device)
+        cfg = _Config(self.B, self.N, self.N_gait, self.device, self.dt_mpc, self.T_gait, self.dt_wbc)
+        self._handle = _vp()
+        _check(self._lib.qrw_create(C.byref(cfg), C.byref(self._handle)), "qrw_create")
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.qrw_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------ device-resident API (torch tensors)
+    @staticmethod
+    def _dev(t, shape):
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise QrwError("expected a contiguous float64 CUDA tensor")
+        if tuple(t.shape) != tuple(shape):
+            raise QrwError("bad shape %s, expected %s" % (tuple(t.shape), tuple(shape)))
+        return _vp(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        import torch
+
+        return _vp(torch.cuda.current_stream().cuda_stream)
+
+    def mpc_solve(self, xref, fsteps, num_iter, out=None):
+        """xref (B,12,N+1), fsteps (B,N_gait,12) CUDA float64; num_iter int or CUDA int32 (B,). Returns (B,24,N)."""
+        import torch
+
+        if out is None:
+            out = torch.empty((self.B, 24, self.N), dtype=torch.float64, device=xref.device)
+        ni_ptr, ni = _vp(0), 0
+        if isinstance(num_iter, torch.Tensor):
+            if num_iter.dtype != torch.int32 or not num_iter.is_cuda or tuple(num_iter.shape) != (self.B,):
+                raise QrwError("num_iter tensor must be CUDA int32 of shape (B,)")
+            ni_ptr = _vp(num_iter.data_ptr())
+        else:
+            ni = int(num_iter)
+        _check(self._lib.qrw_mpc_solve(self._handle, self._dev(xref, (self.B, 12, self.N + 1)),
+                                       self._dev(fsteps, (self.B, self.N_gait, 12)), ni_ptr, ni,
+                                       self._dev(out, (self.B, 24, self.N)), self._stream()), "qrw_mpc_solve")
+        return out
+
+    def wbc_compute(self, q, dq, f_cmd, contacts, pgoals, vgoals, agoals, out=None):
+        """All inputs CUDA float64 with leading dim B. Returns dict of CUDA tensors."""
+        import torch
+
+        B = self.B
+        if out is None:
+            dev = q.device
+            out = dict(tau_ff=torch.empty((B, 12), dtype=torch.float64, device=dev),
+                       qdes=torch.empty((B, 19), dtype=torch.float64, device=dev),
+                       vdes=torch.empty((B, 18), dtype=torch.float64, device=dev),
+                       f_with_delta=torch.empty((B, 12), dtype=torch.float64, device=dev),
+                       ddq_res=torch.empty((B, 6), dtype=torch.float64, device=dev),
+                       feet=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev))
+        _check(self._lib.qrw_wbc_compute(
+            self._handle, self._dev(q, (B, 19)), self._dev(dq, (B, 18)), self._dev(f_cmd, (B, 12)),
+            self._dev(contacts, (B, 4)), self._dev(pgoals, (B, 3, 4)), self._dev(vgoals, (B, 3, 4)),
+            self._dev(agoals, (B, 3, 4)), self._dev(out["tau_ff"], (B, 12)), self._dev(out["qdes"], (B, 19)),
+            self._dev(out["vdes"], (B, 18)), self._dev(out["f_with_delta"], (B, 12)),
+            self._dev(out["ddq_res"], (B, 6)), self._dev(out["feet"], (B, 3, 3, 4)), self._stream()),
+            "qrw_wbc_compute")
+        return out
+
+    # ------------------------------------------------ host-buffer API (numpy)
+    def mpc_solve_host(self, xref, fsteps, num_iter):
+        xref = _h(xref, (self.B, 12, self.N + 1))
+        fsteps = _h(fsteps, (self.B, self.N_gait, 12))
+        out = np.empty((self.B, 24, self.N))
+        ni_arr, ni = None, 0
+        if np.ndim(num_iter) > 0:
+            ni_arr = np.ascontiguousarray(num_iter, dtype=np.int32).reshape(self.B)
+        else:
+            ni = int(num_iter)
+        _check(self._lib.qrw_mpc_solve_host(self._handle, _p(xref), _p(fsteps),
+                                            ni_arr.ctypes.data_as(_ip) if ni_arr is not None else None, ni, _p(out)),
+               "qrw_mpc_solve_host")
+        return out
+
+    def wbc_compute_host(self, q, dq, f_cmd, contacts, pgoals, vgoals, agoals):
+        B = self.B
+        a = [_h(q, (B, 19)), _h(dq, (B, 18)), _h(f_cmd, (B, 12)), _h(contacts, (B, 4)), _h(pgoals, (B, 3, 4)),
+             _h(vgoals, (B, 3, 4)), _h(agoals, (B, 3, 4))]
+        o = dict(tau_ff=np.empty((B, 12)), qdes=np.empty((B, 19)), vdes=np.empty((B, 18)),
+                 f_with_delta=np.empty((B, 12)), ddq_res=np.empty((B, 6)), feet=np.empty((B, 3, 3, 4)))
+        _check(self._lib.qrw_wbc_compute_host(self._handle, *[_p(x) for x in a], _p(o["tau_ff"]), _p(o["qdes"]),
+                                              _p(o["vdes"]), _p(o["f_with_delta"]), _p(o["ddq_res"]), _p(o["feet"])),
+               "qrw_wbc_compute_host")
+        return o
+
+    def fixed_feet_host(self, q12, dq12):
+        B = self.B
+        posf, vf, wf, af = (np.empty((B, 4, 3)) for _ in range(4))
+        Jf = np.empty((B, 12, 12))
+        _check(self._lib.qrw_fixed_feet_host(self._handle, _p(_h(q12, (B, 12))), _p(_h(dq12, (B, 12))), _p(posf),
+                                             _p(vf), _p(wf), _p(af), _p(Jf)), "qrw_fixed_feet_host")
+        return posf, vf, wf, af, Jf
+
+    def invkin_host(self, contacts, goals, vgoals, agoals, posf, vf, wf, af, Jf):
+        B = self.B
+        a = [_h(contacts, (B, 4)), _h(goals, (B, 3, 4)), _h(vgoals, (B, 3, 4)), _h(agoals, (B, 3, 4)),
+             _h(posf, (B, 4, 3)), _h(vf, (B, 4, 3)), _h(wf, (B, 4, 3)), _h(af, (B, 4, 3)), _h(Jf, (B, 12, 12))]
+        ddq, dq_cmd, q_step = np.empty((B, 12)), np.empty((B, 12)), np.empty((B, 12))
+        _check(self._lib.qrw_invkin_host(self._handle, *[_p(x) for x in a], _p(ddq), _p(dq_cmd), _p(q_step)),
+               "qrw_invkin_host")
+        return ddq, dq_cmd, q_step
+
+    def qpwbc_host(self, M, Jc, f_cmd, RNEA, want_H=True):
+        B = self.B
+        f_res, ddq_res = np.empty((B, 12)), np.empty((B, 6))
+        H = np.empty((B, 12, 12)) if want_H else None
+        _check(self._lib.qrw_qpwbc_host(self._handle, _p(_h(M, (B, 18, 18))), _p(_h(Jc, (B, 12, 18))),
+                                        _p(_h(f_cmd, (B, 12))), _p(_h(RNEA, (B, 6))), _p(f_res), _p(ddq_res), _p(H)),
+               "qrw_qpwbc_host")
+        return f_res, ddq_res, H
+
+    # ------------------------------------------------ getters / diagnostics
+    def mpc_gait(self, b=0):
+        gait, S = np.empty((self.N_gait, 4)), np.empty(12 * self.N)
+        _check(self._lib.qrw_mpc_get_gait(self._handle, int(b), _p(gait), _p(S)), "qrw_mpc_get_gait")
+        return gait, S.reshape(-1, 1)
+
+    def mpc_stats(self):
+        it, st = np.empty(self.B, np.int32), np.empty(self.B, np.int32)
+        rho, pri, dua = np.empty(self.B), np.empty(self.B), np.empty(self.B)
+        _check(self._lib.qrw_mpc_get_stats(self._handle, it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _p(rho),
+                                           _p(pri), _p(dua)), "qrw_mpc_get_stats")
+        return dict(iters=it, status=st, rho=rho, pri_res=pri, dua_res=dua)
+
+    def mpc_state(self, b=0):
+        N = self.N
+        x, z, y, D, E = np.empty(24 * N), np.empty(44 * N), np.empty(44 * N), np.empty(24 * N), np.empty(44 * N)
+        c = C.c_double(0.0)
+        _check(self._lib.qrw_mpc_get_state(self._handle, int(b), _p(x), _p(z), _p(y), _p(D), _p(E), C.byref(c)),
+               "qrw_mpc_get_state")
+        return dict(x=x, z=z, y=y, D=D, E=E, c=c.value)
+
+    def wbc_stats(self):
+        it, st = np.empty(self.B, np.int32), np.empty(self.B, np.int32)
+        rho, ksc = np.empty(self.B), np.empty((self.B, 4))
+        _check(self._lib.qrw_wbc_get_stats(self._handle, it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _p(rho),
+                                           _p(ksc)), "qrw_wbc_get_stats")
+        return dict(iters=it, status=st, rho=rho, k_since_contact=ksc)
+
+    def base_inertia_diag(self):
+        Y = np.empty(6)
+        _check(self._lib.qrw_get_base_inertia_diag(self._handle, _p(Y)), "qrw_get_base_inertia_diag")
+        return Y
+
+    def state_bytes(self):
+        return int(self._lib.qrw_state_bytes(self._handle))
