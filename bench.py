@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — control-steps/sec (MPC + WBC) of the MI355X hot path on synthetic Solo12 trot states.
+
+One "step" = one MPC::run + one wbc_controller.compute for every instance of the batch
+(ratio 1:1).  Default workload = BASELINE.json configs[2]: batch 4096, N = 16,
+trot, MPC + QPWBC + InvKin on one MI355X.  With --gpus N every rank owns its own 4096 instances
+(weak scaling) and the results are all-gathered (RCCL over xGMI) every step.
+
+Prints ONE JSON line (rank 0): metric/value/unit/... plus
+  roofline     — dominant kernel (mpc_solve_kernel): algorithmic FP64 flops per launch (measured ADMM
+                 iteration counts x SURVEY §8(d) per-iteration figure) / its average duration measured
+                 with HIP events on the launch stream, against the gfx950 FP64 peak;
+  cpu_baseline — the CPU oracle (oracle/, "port", -O3 -march=native, OpenMP) timed on a bounded sample
+                 of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic work per unit (SURVEY.md §8(d), N = 16; DESIGN.md restates them)
+F_ITER = 64.8e3      # flops per ADMM iteration of one MPC instance
+F_FAC = 0.33e6       # flops per KKT factorisation
+F_ASM = 3.0e3        # assembly
+F_WBC = 15.0e3       # kinematics + 2x RNEA + InvKin + QP build
+F_WBC_IT = 1.0e3     # per 12-variable ADMM iteration
+B_ALG = 36.4e3       # compulsory bytes per control step
+PEAK_FP64 = 78.6e12  # gfx950 FP64 vector = matrix peak
+PEAK_HBM = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--n-steps", type=int, default=16, help="MPC horizon")
+    ap.add_argument("--gaits", type=str, default="trot")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="instances in the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16 cores)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import qrw_hip
+    import synth
+    from sharding import ResultGatherer, pack_results
+
+    B, N = args.batch, args.n_steps
+    N_gait = max(20, N + 4)
+    W, K = max(args.warmup, 1), args.steps  # the first call (num_iter == 0) is the QP setup: always untimed
+    gaits = tuple(args.gaits.split(","))
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K, b0=rank * B)
+    t_gen = time.time()
+    steps = [sb.step(s) for s in range(W + K)]
+    t_gen = time.time() - t_gen
+
+    def dev_t(key):
+        return [torch.from_numpy(np.ascontiguousarray(st[key])).to(dev) for st in steps]
+
+    xref, fsteps = dev_t("xref"), dev_t("fsteps")
+    q, dq, contacts = dev_t("q"), dev_t("dq"), dev_t("contacts")
+    pg, vg, ag = dev_t("pgoals"), dev_t("vgoals"), dev_t("agoals")
+
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=local_rank)
+    mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
+    f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
+    wbc_out = None
+    gather = ResultGatherer(B, 48, dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    ev_w = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    it_mpc, it_wbc = [], []
+
+    def one_step(s, timed_idx=None):
+        nonlocal wbc_out
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
+        eng.mpc_solve(xref[s], fsteps[s], s, out=mpc_out)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
+        f_cmd.copy_(mpc_out[:, 12:, 0])
+        if timed_idx is not None:
+            ev_w[timed_idx][0].record()
+        wbc_out = eng.wbc_compute(q[s], dq[s], f_cmd, contacts[s], pg[s], vg[s], ag[s], out=wbc_out)
+        if timed_idx is not None:
+            ev_w[timed_idx][1].record()
+        if world > 1:
+            gather.gather(pack_results(wbc_out["tau_ff"], wbc_out["f_with_delta"], wbc_out["qdes"], wbc_out["vdes"]))
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(W):
+        one_step(s)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one_step(W + i, i)
+        # iteration counts are read back AFTER the timed region (they stay on the device)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel figures (rank 0): durations from the HIP events, iteration counts of the LAST step
+    mpc_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    wbc_ms = np.array([a.elapsed_time(b) for a, b in ev_w])
+    ms = eng.mpc_stats()
+    ws = eng.wbc_stats()
+    n_ok = int((ms["status"] == 1).sum())
+    # iteration counts differ per step; replay the stats of the last step as representative and
+    # scale the flops of every timed launch by its own duration share
+    flops_launch = float(ms["iters"].astype(np.float64).sum() * F_ITER + B * (F_FAC + F_ASM))
+    dur = float(mpc_ms[-1]) * 1e-3
+    achieved = flops_launch / dur
+    total_steps = world * B * K
+    value = total_steps / elapsed
+
+    out = {
+        "metric": "control-steps/sec (MPC+WBC)", "value": value, "unit": "steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Solo12 %s, batch %d per GPU, horizon N=%d, MPC (OSQP-style ADMM) + WBC (InvKin + "
+                               "RNEA + box-QP) per control step, ratio 1:1" % ("/".join(gaits), B, N),
+                   "batch_per_gpu": B, "n_steps": N, "gaits": list(gaits), "parallelism": "batch-sharded x%d" % world},
+        "roofline": {"kernel": "mpc_solve_kernel", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP64 / 1e12,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": None,
+                     "launch_ms": float(mpc_ms[-1]), "launch_ms_mean": float(mpc_ms.mean()),
+                     "mean_admm_iters": float(ms["iters"].mean()), "max_admm_iters": int(ms["iters"].max()),
+                     "hbm_frac_algorithmic": (B * B_ALG / dur) / PEAK_HBM},
+        "kernels_ms": {"mpc_solve_kernel": float(mpc_ms.mean()), "wbc_kernel": float(wbc_ms.mean())},
+        "solver": {"mpc_solved": n_ok, "mpc_instances": B, "wbc_mean_iters": float(ws["iters"].mean())},
+        "mpc_solves_per_s": world * B * K / (mpc_ms.sum() * 1e-3) if world == 1 else None,
+        "wbc_steps_per_s": world * B * K / (wbc_ms.sum() * 1e-3) if world == 1 else None,
+        "input_gen_s": t_gen,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
+    """CPU restatement (oracle/, 'port') on a bounded sample of the same workload: Bc instances x `steps`
+    receding-horizon control steps (the first one, which sets the QP up, is excluded like the GPU warm-up),
+    one instance per OpenMP thread over all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build(fast=True)
+    cores = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+    sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps + 1)
+    mpc = oracle.MPCBatch(Bc, 0.02, N, 0.02 * N, N_gait, fast=True)
+    wbc = oracle.WbcBatch(Bc, 0.002, fast=True)
+    t_mpc = t_wbc = 0.0
+    for s in range(steps + 1):
+        d = sb.step(s)
+        a = time.perf_counter()
+        r = mpc.run(s, d["xref"], d["fsteps"], cores)
+        b = time.perf_counter()
+        wbc.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"],
+                    d["agoals"], cores)
+        c = time.perf_counter()
+        if s > 0:
+            t_mpc += b - a
+            t_wbc += c - b
+    tot = t_mpc + t_wbc
+    return {"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d instances x %d control steps (after the set-up step), CPU restatement oracle/ "
+                      "(OSQP-0.6-style, not OSQP itself), gcc -O3 -march=native, OpenMP one instance per thread" % (Bc, steps),
+            "mpc_s": t_mpc, "wbc_s": t_wbc}
+
+
+if __name__ == "__main__":
+    main()

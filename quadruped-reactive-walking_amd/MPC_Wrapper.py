@@ -1,0 +1,199 @@
+"""Drop-in for scripts/MPC_Wrapper.py (class MPC_Wrapper): same constructor, solve(),
+get_latest_result(), stop_parallel_loop() and first-iteration default result, with the OSQP
+MPC running as one gfx950 kernel launch (libqrw_hip.so) instead of the bound C++ class.
+
+  multiprocessing=False  the solve is synchronous, as scripts/MPC_Wrapper.py:128-148.
+  multiprocessing=True   the reference runs the MPC in a child process polled through shared
+                         flags (:150-225); here the solve is enqueued on its own HIP stream and
+                         get_latest_result() returns the new result once its event has completed,
+                         the previous one otherwise — the same observable protocol without a
+                         second process.
+The Crocoddyl variant (mpc_type=False) is outside the accelerated hot path.
+
+MPC_Wrapper_batch is the batched variant: solve_batch / get_latest_result_batch over B
+instances with device tensors.
+"""
+import numpy as np
+
+import libquadruped_reactive_walking as MPC
+import qrw_hip
+
+
+def quaternionToRPY(quat):
+    """Quaternion (x, y, z, w) to roll-pitch-yaw (3 x 1) — scripts/utils_mpc.py:37-71."""
+    qx, qy, qz, qw = [float(v) for v in np.asarray(quat).ravel()[:4]]
+    rotateXa0 = 2.0 * (qy * qz + qw * qx)
+    rotateXa1 = qw * qw - qx * qx - qy * qy + qz * qz
+    rotateX = 0.0
+    if (rotateXa0 != 0.0) and (rotateXa1 != 0.0):
+        rotateX = np.arctan2(rotateXa0, rotateXa1)
+    rotateYa0 = -2.0 * (qx * qz - qw * qy)
+    if rotateYa0 >= 1.0:
+        rotateY = np.pi / 2.0
+    elif rotateYa0 <= -1.0:
+        rotateY = -np.pi / 2.0
+    else:
+        rotateY = np.arcsin(rotateYa0)
+    rotateZa0 = 2.0 * (qx * qy + qw * qz)
+    rotateZa1 = qw * qw + qx * qx - qy * qy - qz * qz
+    rotateZ = 0.0
+    if (rotateZa0 != 0.0) and (rotateZa1 != 0.0):
+        rotateZ = np.arctan2(rotateZa0, rotateZa1)
+    return np.array([[rotateX], [rotateY], [rotateZ]])
+
+
+class Dummy:
+    """Dummy class to store variables"""
+
+    def __init__(self):
+        self.xref = None  # Desired trajectory
+        self.fsteps = None  # Desired location of footsteps
+
+
+class MPC_Wrapper:
+    """Wrapper of the OSQP MPC (scripts/MPC_Wrapper.py:20-71).
+
+    Args:
+        mpc_type (bool): True to have PA's MPC (the only one accelerated), False for Crocoddyl
+        dt (float): Time step of the MPC
+        n_steps (int): Number of time steps in one gait cycle
+        k_mpc (int): Number of inv dyn time step for one iteration of the MPC
+        T_gait (float): Duration of one period of gait
+        N_gait (int): number of rows of the gait / fsteps matrices
+        q_init (array): the default position of the robot
+        multiprocessing (bool): asynchronous solve (own HIP stream instead of a child process)
+    """
+
+    def __init__(self, mpc_type, dt, n_steps, k_mpc, T_gait, N_gait, q_init, multiprocessing=False):
+        if not mpc_type:
+            raise NotImplementedError("the Crocoddyl MPC (scripts/crocoddyl_class) is outside the accelerated path")
+        self.f_applied = np.zeros((12,))
+        self.not_first_iter = False
+        self.k_mpc = k_mpc
+        self.dt = dt
+        self.n_steps = int(n_steps)
+        self.T_gait = T_gait
+        self.N_gait = int(N_gait)
+        self.gait_memory = np.zeros(4)
+        self.mpc_type = mpc_type
+        self.multiprocessing = multiprocessing
+        if multiprocessing:
+            import torch
+
+            self._torch = torch
+            self._b = qrw_hip.Batch(1, n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt),
+                                    T_gait=float(T_gait))
+            self._stream = torch.cuda.Stream()
+            self._event = None
+            self._pending = None
+        else:
+            # Create the new version of the MPC solver object (scripts/MPC_Wrapper.py:58-61)
+            self.mpc = MPC.MPC(dt, n_steps, T_gait, self.N_gait)
+
+        # Setup initial result for the first iteration of the main control loop (:64-71)
+        q_init = np.asarray(q_init, dtype=np.float64)
+        x_init = np.zeros(12)
+        x_init[0:3] = q_init[0:3, 0]
+        x_init[3:6] = quaternionToRPY(q_init[3:7, 0]).ravel()
+        self.last_available_result = np.zeros((24, self.n_steps))
+        self.last_available_result[:, 0] = np.hstack((x_init, np.array([0.0, 0.0, 8.0] * 4)))
+
+    def solve(self, k, xref, fsteps, gait):
+        """scripts/MPC_Wrapper.py:73-104."""
+        if self.multiprocessing:
+            self.run_MPC_asynchronous(k, xref, fsteps)
+        else:
+            self.run_MPC_synchronous(k, xref, fsteps)
+
+        if k > 2:
+            self.last_available_result[12:(12 + self.n_steps), :] = np.roll(
+                self.last_available_result[12:(12 + self.n_steps), :], -1, axis=1)
+
+        pt = 0
+        while (np.any(gait[pt, :])):
+            pt += 1
+        if k > 2 and not np.array_equal(gait[0, :], gait[pt - 1, :]):
+            mass = 2.5
+            nb_ctc = np.sum(gait[pt - 1, :])
+            F = 9.81 * mass / nb_ctc
+            self.last_available_result[12:, self.n_steps - 1] = np.zeros(12)
+            for i in range(4):
+                if (gait[pt - 1, i] == 1):
+                    self.last_available_result[12 + 3 * i + 2, self.n_steps - 1] = F
+        return 0
+
+    def get_latest_result(self):
+        """scripts/MPC_Wrapper.py:106-126."""
+        if (self.not_first_iter):
+            if self.multiprocessing:
+                if self._event is not None and self._event.query():
+                    self.last_available_result = self._pending.cpu().numpy()[0].copy()
+                    self._event = None
+                return self.last_available_result
+            else:
+                return self.f_applied
+        else:
+            self.not_first_iter = True
+            return self.last_available_result
+
+    def run_MPC_synchronous(self, k, xref, fsteps):
+        """scripts/MPC_Wrapper.py:128-148."""
+        self.mpc.run(int(k), xref.copy(), fsteps.copy())
+
+        # Output of the MPC
+        self.f_applied = self.mpc.get_latest_result()
+
+    def run_MPC_asynchronous(self, k, xref, fsteps):
+        """scripts/MPC_Wrapper.py:150-168, :186-223 — num_iter is k / k_mpc there (:235)."""
+        torch = self._torch
+        fsteps = np.asarray(fsteps, dtype=np.float64).copy()
+        fsteps[np.isnan(fsteps)] = 0.0
+        if self._event is not None:
+            self._event.synchronize()  # one solve in flight, like the single child process
+        with torch.cuda.stream(self._stream):
+            dx = torch.from_numpy(np.ascontiguousarray(np.asarray(xref, dtype=np.float64))[None]).cuda()
+            df = torch.from_numpy(np.ascontiguousarray(fsteps)[None]).cuda()
+            self._pending = self._b.mpc_solve(dx, df, int(k / self.k_mpc))
+            self._event = torch.cuda.Event()
+            self._event.record(self._stream)
+        return 0
+
+    def stop_parallel_loop(self):
+        """scripts/MPC_Wrapper.py:300-306 — nothing to stop: there is no child process."""
+        if self.multiprocessing and self._event is not None:
+            self._event.synchronize()
+        return 0
+
+
+class MPC_Wrapper_batch:
+    """B instances, device-resident. solve_batch(k, xref (B,12,N+1), fsteps (B,N_gait,12)) runs one MPC
+    iteration for every instance on the caller's stream; get_latest_result_batch() -> (B,24,N).
+    Before the first solve it returns the reference's default result (scripts/MPC_Wrapper.py:64-71)."""
+
+    def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0):
+        import torch
+
+        self._torch = torch
+        self.B, self.n_steps, self.N_gait = int(batch), int(n_steps), int(N_gait)
+        self._b = qrw_hip.Batch(self.B, n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt),
+                                T_gait=float(T_gait), device=device)
+        first = np.zeros((self.B, 24, self.n_steps))
+        if q_init is not None:
+            q_init = np.asarray(q_init, dtype=np.float64).reshape(self.B, 19)
+            first[:, 0:3, 0] = q_init[:, 0:3]
+            for b in range(self.B):
+                first[b, 3:6, 0] = quaternionToRPY(q_init[b, 3:7]).ravel()
+        first[:, 12:, 0] = np.array([0.0, 0.0, 8.0] * 4)
+        self._result = torch.from_numpy(first).to("cuda:%d" % device)
+        self._out = None
+
+    def solve_batch(self, k, xref, fsteps):
+        self._out = self._b.mpc_solve(xref, fsteps, k, out=self._out)
+        self._result = self._out
+        return 0
+
+    def get_latest_result_batch(self):
+        return self._result
+
+    def stats(self):
+        return self._b.mpc_stats()

@@ -5,7 +5,7 @@
 //   the 36 B coefficients + 12 S flags per step vary; the sparsity is compile-time here),
 //   create_NK/update_NK :261-312/:469-496, create_weight_matrices :317-391, call_solver
 //   :501-564 (OSQP 0.6.x: scale_data, osqp_update_A/bounds, osqp_solve — restated from the
-//   published algorithm, see oracle/osqp_restate.h) and retrieve_result :569-599.
+//   published algorithm and the 0.6.x source structure) and retrieve_result :569-599.
 //
 // Mapping: ONE WAVEFRONT PER ROBOT INSTANCE, lane = 4*k + j with k = horizon step, j = foot.
 // Lane (k,j) owns state entries X_k[3j..3j+2], force entries f_k[3j..3j+2], dynamics rows

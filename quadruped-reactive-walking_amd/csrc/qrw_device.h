@@ -7,7 +7,7 @@ namespace qrw {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// ---- OSQP constants restated (third-party, osqp constants.h 0.6.x; see oracle/osqp_restate.h)
+// ---- OSQP constants restated (third-party dependency of the reference, osqp constants.h 0.6.x)
 constexpr double kOsqpInfty = 1e30;
 constexpr double kRhoMin = 1e-6;
 constexpr double kRhoMax = 1e6;

@@ -16,7 +16,7 @@
 //
 // Rigid-body formulation: classical Newton-Euler in base-frame coordinates (angular velocity /
 // acceleration, CoM accelerations, per-link force and moment), NOT the spatial-algebra recursion
-// the CPU oracle restates from Pinocchio — the two only share include/qrw_solo12_model.h.
+// Pinocchio uses — only the model constants (include/qrw_solo12_model.h) are shared with the test checker.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures of tests/golden/ from the CPU oracle.
+
+The reference holds NO golden vectors for this path and cannot be built or imported here
+(parity unpinned), so these vectors come from the oracle (oracle/, the CPU
+restatement) on seeded synthetic inputs.  Schema mirrors the reference's logger names
+(scripts/LoggerControl.py:141-164): planner_xref, planner_fsteps, planner_gait, mpc_x_f,
+wbc_tau_ff, wbc_f_ctc, ...
+
+    python tests/golden/make_golden.py          # rewrites the .npz files next to this script
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd"), os.path.join(ROOT, "oracle")]
+import oracle  # noqa: E402
+import synth  # noqa: E402
+
+
+def make(name, N, gaits, B, steps, seed0):
+    N_gait = max(20, N + 4)
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, seed0=seed0)
+    mpcs = [oracle.MPC(0.02, N, 0.02 * N, N_gait) for _ in range(B)]
+    wbcs = [oracle.WbcController(0.002) for _ in range(B)]
+    rec = {k: [] for k in ("planner_xref", "planner_fsteps", "planner_gait", "mpc_x_f", "mpc_iters", "mpc_status",
+                           "mpc_rho", "wbc_q", "wbc_dq", "wbc_contacts", "wbc_pgoals", "wbc_vgoals", "wbc_agoals",
+                           "wbc_f_cmd", "wbc_tau_ff", "wbc_f_ctc", "wbc_qdes", "wbc_vdes", "wbc_ddq_res",
+                           "wbc_iters")}
+    x0 = None
+    for s in range(steps):
+        d = sb.step(s, x0)
+        xf = np.zeros((B, 24, N))
+        its, sts, rhos = np.zeros(B, int), np.zeros(B, int), np.zeros(B)
+        tau, f, qd, vd, dd, wit = np.zeros((B, 12)), np.zeros((B, 12)), np.zeros((B, 19)), np.zeros((B, 18)), \
+            np.zeros((B, 6)), np.zeros(B, int)
+        for b in range(B):
+            mpcs[b].run(s, d["xref"][b], d["fsteps"][b])
+            xf[b] = mpcs[b].get_latest_result()
+            its[b], sts[b], rhos[b] = mpcs[b].iter, mpcs[b].status, mpcs[b].rho
+            wbcs[b].compute(d["q"][b], d["dq"][b], xf[b, 12:, 0], d["contacts"][b], d["pgoals"][b], d["vgoals"][b],
+                            d["agoals"][b])
+            tau[b], f[b], qd[b], vd[b], dd[b] = wbcs[b].tau_ff, wbcs[b].f_with_delta[:, 0], wbcs[b].qdes, \
+                wbcs[b].vdes[:, 0], wbcs[b].ddq_res
+            wit[b] = wbcs[b].qp_iter
+        x0 = xf[:, :12, 0]
+        for k, v in (("planner_xref", d["xref"]), ("planner_fsteps", d["fsteps"]), ("planner_gait", d["gait"]),
+                     ("mpc_x_f", xf), ("mpc_iters", its), ("mpc_status", sts), ("mpc_rho", rhos), ("wbc_q", d["q"]),
+                     ("wbc_dq", d["dq"]), ("wbc_contacts", d["contacts"]), ("wbc_pgoals", d["pgoals"]),
+                     ("wbc_vgoals", d["vgoals"]), ("wbc_agoals", d["agoals"]), ("wbc_f_cmd", xf[:, 12:, 0]),
+                     ("wbc_tau_ff", tau), ("wbc_f_ctc", f), ("wbc_qdes", qd), ("wbc_vdes", vd), ("wbc_ddq_res", dd),
+                     ("wbc_iters", wit)):
+            rec[k].append(np.array(v))
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out["meta"] = np.array([N, N_gait, B, steps, seed0])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: v.shape for k, v in out.items() if k in ("mpc_x_f", "wbc_tau_ff")}, "iters", out["mpc_iters"].ravel())
+
+
+if __name__ == "__main__":
+    oracle.build()
+    make("control_trot_n16.npz", 16, ("trot",), 2, 5, 777000)
+    make("control_mixed_n16.npz", 16, ("walk", "bounding", "pacing"), 3, 4, 778000)
+    make("control_trot_n8.npz", 8, ("trot",), 2, 3, 779000)

