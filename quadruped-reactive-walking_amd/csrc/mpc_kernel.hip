@@ -31,11 +31,12 @@ namespace qrw {
 namespace {
 
 constexpr int kMatSz = 144;
+constexpr int kSlot = 152;  // chain-matrix slot: 144 entries + zero pad (branch-free operand loads for MFMA rows 12..15)
 constexpr int kWSz = 36;
 
 // LDS carve (doubles). Chain matrices -N_k (k = 1..N-1), exchange vector, factor scratch.
 struct MpcLds {
-  double sN[(kMpcMaxN - 1) * kMatSz];
+  double sN[(kMpcMaxN - 1) * kSlot];
   double sX[kMpcMaxN * 12];
   double sW[kMpcMaxN * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
   double sOm[kMpcMaxN * 12];    // omega_D per step (factor phase)
@@ -45,6 +46,13 @@ struct MpcLds {
 };
 
 __device__ __forceinline__ void wg_sync() { __syncthreads(); }
+#ifdef QRW_PROFILE_PHASES
+#define PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0,0,0,0,0,0,0,0,0,0};
+#define PH(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } while (0)
+#else
+#define PH_DECL
+#define PH(i)
+#endif
 
 // ---- friction-cone block helpers (rows: fx-mu fz, -fx-mu fz, fy-mu fz, -fy-mu fz, -fz; MPC.cpp:130-146)
 __device__ __forceinline__ void cone_apply(const double f[3], double mu, double out[5]) {
@@ -64,7 +72,9 @@ __device__ __forceinline__ void cone_apply_t(const double w[5], double mu, doubl
 
 __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   __shared__ MpcLds L;
-  const int b = blockIdx.x;
+  // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
+  // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
+  const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   const int k = lane >> 2, j = lane & 3;
   const int N = a.N;
@@ -72,6 +82,16 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   const bool has_next = act && (k + 1 < N);
   const bool has_prev = act && (k > 0);
   const int mrow = lane & 15, mq = lane >> 4;  // MFMA operand coordinates
+  // A-operand offsets inside a chain-matrix slot (column-major 12x12): rows 12..15 of the 16-row MFMA tile read
+  // the slot's zero pad, so the loads in the sweeps are unconditional.
+  const int offA_f0 = (mrow < 12) ? (0 + mq) * 12 + mrow : kMatSz;
+  const int offA_f1 = (mrow < 12) ? 4 * 12 : 0;   // relative to offA_f0
+  const int offA_f2 = (mrow < 12) ? 8 * 12 : 0;
+  const int offA_b0 = (mrow < 12) ? mrow * 12 + (0 + mq) : kMatSz;  // transposed read
+  const int offA_b1 = (mrow < 12) ? 4 : 0;
+  const int offA_b2 = (mrow < 12) ? 8 : 0;
+  for (int e = lane; e < (kMpcMaxN - 1) * (kSlot - kMatSz); e += 64)
+    L.sN[(e / (kSlot - kMatSz)) * kSlot + kMatSz + e % (kSlot - kMatSz)] = 0.0;
 
   // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
   const double dt = a.dt;
@@ -339,6 +359,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 
   // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
+  PH_DECL
   bool need_factor = true;
   int iter = 0, status = kStatusUnsolved, rho_updates = 0;
   double pri_res = 0.0, dua_res = 0.0;
@@ -346,6 +367,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   rho = fmin(fmax(rho, kRhoMin), kRhoMax);
 
   for (iter = 1; iter <= max_iter; iter++) {
+    PH(9);
     if (need_factor) {
       need_factor = false;
       const double rho_eq = kRhoEqOverIneq * rho;
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
                 for (int m = 0; m < 6; m++) v += Wk[(i - 6) * 6 + m] * Mprev[(6 + m) * 12 + ip];
               }
-              L.sN[(kk - 1) * kMatSz + ip * 12 + i] = -v;
+              L.sN[(kk - 1) * kSlot + ip * 12 + i] = -v;
             }
           }
           wg_sync();
@@ -502,7 +524,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
               if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
             }
             if (kk > 0) {  // + (-N)[i][m] * C[ip][m]
-              const double* nN = &L.sN[(kk - 1) * kMatSz];
+              const double* nN = &L.sN[(kk - 1) * kSlot];
               double acc = -om[ip] * nN[ip * 12 + i];
               if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * 12 + i];
               else {
@@ -546,6 +568,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
         wg_sync();
       }
+    PH(0);
     }  // need_factor
 
     const double rho_eq = kRhoEqOverIneq * rho;
@@ -584,6 +607,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         rF[t] = sigma * xF[t] * iDf[t] + v;
       }
     }
+    PH(1);
     // ---- 2. eliminate forces: r_X[v] -= g_k - g_{k+1}, g_k = Phi_k' r_f,k
     {
       double g[6];
@@ -599,6 +623,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         if (j >= 2) rX[t] += (has_next ? gn : 0.0) - gs;
       }
     }
+    PH(2);
     // ---- 3. block-tridiagonal solve on the matrix cores
     if (act) {
 #pragma unroll
@@ -606,26 +631,42 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     }
     wg_sync();
     {
-      v4d acc;  // forward sweep: u_k = r_k - N_k u_{k-1}
+      // forward sweep u_k = r_k - N_k u_{k-1}; two register sets (P/Q) ping-pong so that the operands of the
+      // next step are in flight while the three MFMAs of the current step run
+      v4d acc;
       acc[0] = L.sX[mq]; acc[1] = L.sX[4 + mq]; acc[2] = L.sX[8 + mq]; acc[3] = 0.0;
-      for (int kk = 1; kk < N; kk++) {
-        const double* nN = &L.sN[(kk - 1) * kMatSz];
-        const double a0 = (mrow < 12) ? nN[(0 + mq) * 12 + mrow] : 0.0;
-        const double a1 = (mrow < 12) ? nN[(4 + mq) * 12 + mrow] : 0.0;
-        const double a2 = (mrow < 12) ? nN[(8 + mq) * 12 + mrow] : 0.0;
-        v4d c;
-        c[0] = L.sX[kk * 12 + mq]; c[1] = L.sX[kk * 12 + 4 + mq]; c[2] = L.sX[kk * 12 + 8 + mq]; c[3] = 0.0;
-        const double b0 = acc[0], b1 = acc[1], b2 = acc[2];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c, 0, 0, 0);
-        acc = c;
-        if (mrow == 0) {
-          L.sX[kk * 12 + mq] = acc[0]; L.sX[kk * 12 + 4 + mq] = acc[1]; L.sX[kk * 12 + 8 + mq] = acc[2];
-        }
+      const double* pa = &L.sN[offA_f0];
+      const double* pc = &L.sX[12 + mq];
+      double* ps = &L.sX[12 + mq];
+      double pA0, pA1, pA2, pC0, pC1, pC2, qA0, qA1, qA2, qC0, qC1, qC2;
+#define QRW_LOAD(A0, A1, A2, C0, C1, C2) \
+  do { A0 = pa[0]; A1 = pa[offA_f1]; A2 = pa[offA_f2]; C0 = pc[0]; C1 = pc[4]; C2 = pc[8]; pa += kSlot; pc += 12; } while (0)
+#define QRW_STEP(A0, A1, A2, C0, C1, C2)                                   \
+  do {                                                                     \
+    v4d c_;                                                                \
+    c_[0] = C0; c_[1] = C1; c_[2] = C2; c_[3] = 0.0;                       \
+    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, acc[0], c_, 0, 0, 0);    \
+    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, acc[1], c_, 0, 0, 0);    \
+    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, acc[2], c_, 0, 0, 0);    \
+    acc = c_;                                                              \
+    ps[0] = acc[0]; ps[4] = acc[1]; ps[8] = acc[2];                        \
+  } while (0)
+      int kk = 1;
+      if (kk < N) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
+#pragma unroll 1
+      for (; kk + 1 < N; kk += 2) {
+        QRW_LOAD(qA0, qA1, qA2, qC0, qC1, qC2);
+        QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
+        ps += 12;
+        if (kk + 2 < N) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
+        QRW_STEP(qA0, qA1, qA2, qC0, qC1, qC2);
+        ps += 12;
       }
+      if (kk < N) QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
+#undef QRW_LOAD
     }
     wg_sync();
+    PH(3);
     {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
       double u[12], v[3];
 #pragma unroll
@@ -644,28 +685,35 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
       }
     }
     wg_sync();
+    PH(4);
     {
-      v4d acc;  // backward sweep: x_k = v_k - N_{k+1}' x_{k+1}
+      // backward sweep x_k = v_k - N_{k+1}' x_{k+1} (transposed read of the same column-major slots)
+      v4d acc;
       const int kl = N - 1;
       acc[0] = L.sX[kl * 12 + mq]; acc[1] = L.sX[kl * 12 + 4 + mq]; acc[2] = L.sX[kl * 12 + 8 + mq]; acc[3] = 0.0;
-      for (int kk = N - 2; kk >= 0; kk--) {
-        const double* nN = &L.sN[kk * kMatSz];  // -N_{kk+1}, column-major; transposed read
-        const double a0 = (mrow < 12) ? nN[mrow * 12 + (0 + mq)] : 0.0;
-        const double a1 = (mrow < 12) ? nN[mrow * 12 + (4 + mq)] : 0.0;
-        const double a2 = (mrow < 12) ? nN[mrow * 12 + (8 + mq)] : 0.0;
-        v4d c;
-        c[0] = L.sX[kk * 12 + mq]; c[1] = L.sX[kk * 12 + 4 + mq]; c[2] = L.sX[kk * 12 + 8 + mq]; c[3] = 0.0;
-        const double b0 = acc[0], b1 = acc[1], b2 = acc[2];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, c, 0, 0, 0);
-        acc = c;
-        if (mrow == 0) {
-          L.sX[kk * 12 + mq] = acc[0]; L.sX[kk * 12 + 4 + mq] = acc[1]; L.sX[kk * 12 + 8 + mq] = acc[2];
-        }
+      const double* pa = &L.sN[(N >= 2 ? N - 2 : 0) * kSlot + offA_b0];
+      const double* pc = &L.sX[(N >= 2 ? N - 2 : 0) * 12 + mq];
+      double* ps = &L.sX[(N >= 2 ? N - 2 : 0) * 12 + mq];
+      double pA0, pA1, pA2, pC0, pC1, pC2, qA0, qA1, qA2, qC0, qC1, qC2;
+#define QRW_LOAD(A0, A1, A2, C0, C1, C2) \
+  do { A0 = pa[0]; A1 = pa[offA_b1]; A2 = pa[offA_b2]; C0 = pc[0]; C1 = pc[4]; C2 = pc[8]; pa -= kSlot; pc -= 12; } while (0)
+      int kk = N - 2;
+      if (kk >= 0) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
+#pragma unroll 1
+      for (; kk - 1 >= 0; kk -= 2) {
+        QRW_LOAD(qA0, qA1, qA2, qC0, qC1, qC2);
+        QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
+        ps -= 12;
+        if (kk - 2 >= 0) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
+        QRW_STEP(qA0, qA1, qA2, qC0, qC1, qC2);
+        ps -= 12;
       }
+      if (kk >= 0) QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
+#undef QRW_LOAD
+#undef QRW_STEP
     }
     wg_sync();
+    PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates
     double Xc[12], Xp[12];
 #pragma unroll
@@ -740,6 +788,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
       zC[c] = zn;
     }
 
+    PH(6);
     // ---- 5. termination / adaptive rho (OSQP update_info, check_termination, adapt_rho)
     const bool check = (iter % 25 == 0);
     if (check) {
@@ -856,6 +905,10 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
       }
     }
   }
+  PH(7);
+#ifdef QRW_PROFILE_PHASES
+  if (lane == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
+#endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved) {
     // max_iter reached: OSQP re-checks with 10x tolerances (check_termination(work, 1))
@@ -906,6 +959,35 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     a.rho_updates[b] = rho_updates;
   }
 #undef ST
+}
+
+// Counting sort of the instances by decreasing iteration count (multiples of 25, at most 4000) -> order[]
+__global__ __launch_bounds__(1024) void mpc_order_kernel(const int* iters, const int* status, int* order, int B) {
+  __shared__ int hist[162];
+  __shared__ int offs[162];
+  for (int i = threadIdx.x; i < 162; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int key = iters[b] / 25;
+    key = key < 0 ? 0 : (key > 160 ? 160 : key);
+    atomicAdd(&hist[key], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int kk = 160; kk >= 0; kk--) { offs[kk] = run; run += hist[kk]; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int key = iters[b] / 25;
+    key = key < 0 ? 0 : (key > 160 ? 160 : key);
+    order[atomicAdd(&offs[key], 1)] = b;
+  }
+}
+
+int mpc_order_launch(const int* iters, const int* status, int* order, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, iters, status, order, B);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {

@@ -39,8 +39,9 @@ struct qrw_handle_s {
   double* mpc_st = nullptr;
   int* mpc_gait = nullptr;
   int* mpc_flags = nullptr;
-  int *mpc_iters = nullptr, *mpc_status = nullptr, *mpc_rho_updates = nullptr;
-  double *mpc_rho = nullptr, *mpc_pri = nullptr, *mpc_dua = nullptr;
+  int *mpc_iters = nullptr, *mpc_status = nullptr, *mpc_rho_updates = nullptr, *mpc_order = nullptr;
+  bool mpc_have_order = false;
+  double *mpc_rho = nullptr, *mpc_pri = nullptr, *mpc_dua = nullptr, *mpc_prof = nullptr;
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -118,9 +119,11 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->mpc_iters, B * sizeof(int));
   ALLOC(h->mpc_status, B * sizeof(int));
   ALLOC(h->mpc_rho_updates, B * sizeof(int));
+  ALLOC(h->mpc_order, B * sizeof(int));
   ALLOC(h->mpc_rho, B * sizeof(double));
   ALLOC(h->mpc_pri, B * sizeof(double));
   ALLOC(h->mpc_dua, B * sizeof(double));
+  ALLOC(h->mpc_prof, B * 10 * sizeof(double));
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
   ALLOC(h->wbc_iters, B * sizeof(int));
   ALLOC(h->wbc_status, B * sizeof(int));
@@ -138,8 +141,8 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
 extern "C" int qrw_destroy(qrw_handle h) {
   if (!h) return 0;
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
-  hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
-  hipFree(h->mpc_dua); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
+  hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
+  hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -160,7 +163,15 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   a.out = d_out; a.st = h->mpc_st; a.gait = h->mpc_gait; a.flags = h->mpc_flags; a.iters = h->mpc_iters;
   a.status = h->mpc_status; a.rho_out = h->mpc_rho; a.pri = h->mpc_pri; a.dua = h->mpc_dua;
   a.rho_updates = h->mpc_rho_updates;
+  a.prof = h->mpc_prof;
+  a.order = h->mpc_have_order ? h->mpc_order : nullptr;
   if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
+  if (h->cfg.batch > 1024) {
+    if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_status, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
+      return fail(-11, "qrw_mpc_solve: order kernel launch failed", hipGetLastError());
+    h->mpc_have_order = true;
+  }
   return 0;
 }
 
@@ -403,4 +414,12 @@ extern "C" int qrw_selftest_mfma(double* max_err) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_mfma: no HIP device");
   return qrw::mfma_selftest(max_err);
+}
+
+// Diagnostic (profiling builds only, -DQRW_PROFILE_PHASES): per-instance shader-clock totals of the MPC kernel phases.
+extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] */) {
+  if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * 10 * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
+  return 0;
 }

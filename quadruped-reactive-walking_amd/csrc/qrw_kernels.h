@@ -54,9 +54,12 @@ struct MpcArgs {
   double* pri;
   double* dua;
   int* rho_updates;
+  const int* order;  // optional [B]: block i solves instance order[i] (longest-first scheduling)
+  double* prof;  // optional [B][10] phase cycle counters (diagnostic builds only)
 };
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
+int mpc_order_launch(const int* iters, const int* status, int* order, int B, hipStream_t stream);
 
 // WBC persistent state: st[instance][item]
 enum WbcStateItem {

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libqrw_hip.so")
+_LIB_PATH = os.environ.get("QRW_HIP_LIB", os.path.join(_HERE, "libqrw_hip.so"))  # override: diagnostic builds
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
