@@ -36,6 +36,7 @@ constexpr int kWSz = 36;
 
 // LDS carve (doubles). Chain matrices -N_k (k = 1..N-1), exchange vector, factor scratch.
 struct MpcLds {
+  double sPad[kSlot];  // the backward sweep's last prefetch reads one slot below sN[0]
   double sN[(kMpcMaxN - 1) * kSlot];
   double sX[kMpcMaxN * 12];
   double sW[kMpcMaxN * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
@@ -67,6 +68,95 @@ __device__ __forceinline__ void cone_apply_t(const double w[5], double mu, doubl
   out[1] = w[2] - w[3];
   out[2] = -mu * (w[0] + w[1] + w[2] + w[3]) - w[4];
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// One sweep of the block-bidiagonal recursion  y_s = c_s + M_s y_{s-1}  (s = 1..steps) on the FP64 matrix cores.
+//   pa        LDS byte address of this lane's A-operand entry of M_1, chunk 0 (chunks 1,2 at +oa1,+oa2)
+//   pc        LDS byte address of c_1[4r + lane/16] (r = 0: +0, r = 1: +32, r = 2: +64)
+//   ps        LDS byte address of y_0[lane/16] (same strides); y_s overwrites c_s in place
+//   dA, dX    byte strides between consecutive steps (matrix slot, 12-vector), signed
+// Hand-scheduled: three operand bundles {A0,A1,A2, C/D tuple} rotate; while the three dependent
+// v_mfma_f64_16x16x4 of step s run (64 cycles each) the result of step s-1 is stored and the operands of step
+// s+1 are fetched.  Hazards: LDS loads -> s_waitcnt at step entry; MFMA D -> next reader 19 wait states.
+// hipcc cannot produce this: with >256 live registers it selects the AGPR form of MFMA and copies the tuple
+// through v_accvgpr_* every step, and it does not model hazards of MFMAs split over asm statements.
+#define QRW_T0 "v[180:187]"
+#define QRW_T1 "v[188:195]"
+#define QRW_T2 "v[196:203]"
+#define QRW_LOADB(A0, A1, A2, TLO, THI)                      \
+  "ds_read_b64 " A0 ", %0\n\t"                               \
+  "ds_read_b64 " A1 ", %1\n\t"                               \
+  "ds_read_b64 " A2 ", %2\n\t"                               \
+  "ds_read2_b64 " TLO ", %3 offset1:4\n\t"                   \
+  "ds_read_b64 " THI ", %3 offset:64\n\t"                    \
+  "v_add_u32 %0, %5, %0\n\t"                                 \
+  "v_add_u32 %1, %5, %1\n\t"                                 \
+  "v_add_u32 %2, %5, %2\n\t"                                 \
+  "v_add_u32 %3, %6, %3\n\t"
+#define QRW_STEPB(TC, A0, A1, A2, P01, P23, P45, LOADNEXT)   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                 \
+  "v_mfma_f64_16x16x4_f64 " TC ", " A0 ", " P01 ", " TC "\n\t" \
+  "ds_write2_b64 %4, " P01 ", " P23 " offset1:4\n\t"         \
+  "ds_write_b64 %4, " P45 " offset:64\n\t"                   \
+  "v_add_u32 %4, %6, %4\n\t"                                 \
+  "v_mfma_f64_16x16x4_f64 " TC ", " A1 ", " P23 ", " TC "\n\t" \
+  LOADNEXT                                                   \
+  "v_mfma_f64_16x16x4_f64 " TC ", " A2 ", " P45 ", " TC "\n\t" \
+  "s_nop 15\n\t"                                             \
+  "s_nop 2\n\t"
+__device__ __forceinline__ void chain_sweep(unsigned pa, int oa1, int oa2, unsigned pc, unsigned ps, int dA, int dX,
+                                            int steps) {
+  unsigned pa1 = pa + oa1, pa2 = pa + oa2;
+  asm volatile(
+      "v_mov_b32 v186, 0\n\tv_mov_b32 v187, 0\n\tv_mov_b32 v194, 0\n\tv_mov_b32 v195, 0\n\t"
+      "v_mov_b32 v202, 0\n\tv_mov_b32 v203, 0\n\t"
+      "ds_read2_b64 v[196:199], %4 offset1:4\n\t"
+      "ds_read_b64 v[200:201], %4 offset:64\n\t"
+      "s_cmp_lt_i32 %7, 1\n\t"
+      "s_cbranch_scc1 9f\n\t"
+      QRW_LOADB("v[204:205]", "v[206:207]", "v[208:209]", "v[180:183]", "v[184:185]")
+      "1:\n\t"
+      QRW_STEPB(QRW_T0, "v[204:205]", "v[206:207]", "v[208:209]", "v[196:197]", "v[198:199]", "v[200:201]",
+                QRW_LOADB("v[210:211]", "v[212:213]", "v[214:215]", "v[188:191]", "v[192:193]"))
+      "s_sub_u32 %7, %7, 1\n\t"
+      "s_cmp_eq_u32 %7, 0\n\t"
+      "s_cbranch_scc1 7f\n\t"
+      QRW_STEPB(QRW_T1, "v[210:211]", "v[212:213]", "v[214:215]", "v[180:181]", "v[182:183]", "v[184:185]",
+                QRW_LOADB("v[216:217]", "v[218:219]", "v[220:221]", "v[196:199]", "v[200:201]"))
+      "s_sub_u32 %7, %7, 1\n\t"
+      "s_cmp_eq_u32 %7, 0\n\t"
+      "s_cbranch_scc1 8f\n\t"
+      QRW_STEPB(QRW_T2, "v[216:217]", "v[218:219]", "v[220:221]", "v[188:189]", "v[190:191]", "v[192:193]",
+                QRW_LOADB("v[204:205]", "v[206:207]", "v[208:209]", "v[180:183]", "v[184:185]"))
+      "s_sub_u32 %7, %7, 1\n\t"
+      "s_cmp_eq_u32 %7, 0\n\t"
+      "s_cbranch_scc0 1b\n\t"
+      "9:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_write2_b64 %4, v[196:197], v[198:199] offset1:4\n\t"
+      "ds_write_b64 %4, v[200:201] offset:64\n\t"
+      "s_branch 6f\n\t"
+      "7:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_write2_b64 %4, v[180:181], v[182:183] offset1:4\n\t"
+      "ds_write_b64 %4, v[184:185] offset:64\n\t"
+      "s_branch 6f\n\t"
+      "8:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_write2_b64 %4, v[188:189], v[190:191] offset1:4\n\t"
+      "ds_write_b64 %4, v[192:193] offset:64\n\t"
+      "6:\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "+v"(pa), "+v"(pa1), "+v"(pa2), "+v"(pc), "+v"(ps), "+s"(dA), "+s"(dX), "+s"(steps)
+      :
+      : "memory", "scc", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191",
+        "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205",
+        "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219",
+        "v220", "v221");
+}
+#undef QRW_LOADB
+#undef QRW_STEPB
 
 }  // namespace
 
@@ -630,41 +720,9 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = rX[t];
     }
     wg_sync();
-    {
-      // forward sweep u_k = r_k - N_k u_{k-1}; two register sets (P/Q) ping-pong so that the operands of the
-      // next step are in flight while the three MFMAs of the current step run
-      v4d acc;
-      acc[0] = L.sX[mq]; acc[1] = L.sX[4 + mq]; acc[2] = L.sX[8 + mq]; acc[3] = 0.0;
-      const double* pa = &L.sN[offA_f0];
-      const double* pc = &L.sX[12 + mq];
-      double* ps = &L.sX[12 + mq];
-      double pA0, pA1, pA2, pC0, pC1, pC2, qA0, qA1, qA2, qC0, qC1, qC2;
-#define QRW_LOAD(A0, A1, A2, C0, C1, C2) \
-  do { A0 = pa[0]; A1 = pa[offA_f1]; A2 = pa[offA_f2]; C0 = pc[0]; C1 = pc[4]; C2 = pc[8]; pa += kSlot; pc += 12; } while (0)
-#define QRW_STEP(A0, A1, A2, C0, C1, C2)                                   \
-  do {                                                                     \
-    v4d c_;                                                                \
-    c_[0] = C0; c_[1] = C1; c_[2] = C2; c_[3] = 0.0;                       \
-    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, acc[0], c_, 0, 0, 0);    \
-    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, acc[1], c_, 0, 0, 0);    \
-    c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, acc[2], c_, 0, 0, 0);    \
-    acc = c_;                                                              \
-    ps[0] = acc[0]; ps[4] = acc[1]; ps[8] = acc[2];                        \
-  } while (0)
-      int kk = 1;
-      if (kk < N) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
-#pragma unroll 1
-      for (; kk + 1 < N; kk += 2) {
-        QRW_LOAD(qA0, qA1, qA2, qC0, qC1, qC2);
-        QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
-        ps += 12;
-        if (kk + 2 < N) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
-        QRW_STEP(qA0, qA1, qA2, qC0, qC1, qC2);
-        ps += 12;
-      }
-      if (kk < N) QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
-#undef QRW_LOAD
-    }
+    // forward sweep u_k = r_k - N_k u_{k-1}, k = 1..N-1 (u_0 = r_0), in place in sX
+    chain_sweep((unsigned)(size_t)&L.sN[offA_f0], offA_f1 * 8, offA_f2 * 8, (unsigned)(size_t)&L.sX[12 + mq],
+                (unsigned)(size_t)&L.sX[mq], kSlot * 8, 96, N - 1);
     wg_sync();
     PH(3);
     {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
@@ -686,32 +744,10 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     }
     wg_sync();
     PH(4);
-    {
-      // backward sweep x_k = v_k - N_{k+1}' x_{k+1} (transposed read of the same column-major slots)
-      v4d acc;
-      const int kl = N - 1;
-      acc[0] = L.sX[kl * 12 + mq]; acc[1] = L.sX[kl * 12 + 4 + mq]; acc[2] = L.sX[kl * 12 + 8 + mq]; acc[3] = 0.0;
-      const double* pa = &L.sN[(N >= 2 ? N - 2 : 0) * kSlot + offA_b0];
-      const double* pc = &L.sX[(N >= 2 ? N - 2 : 0) * 12 + mq];
-      double* ps = &L.sX[(N >= 2 ? N - 2 : 0) * 12 + mq];
-      double pA0, pA1, pA2, pC0, pC1, pC2, qA0, qA1, qA2, qC0, qC1, qC2;
-#define QRW_LOAD(A0, A1, A2, C0, C1, C2) \
-  do { A0 = pa[0]; A1 = pa[offA_b1]; A2 = pa[offA_b2]; C0 = pc[0]; C1 = pc[4]; C2 = pc[8]; pa -= kSlot; pc -= 12; } while (0)
-      int kk = N - 2;
-      if (kk >= 0) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
-#pragma unroll 1
-      for (; kk - 1 >= 0; kk -= 2) {
-        QRW_LOAD(qA0, qA1, qA2, qC0, qC1, qC2);
-        QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
-        ps -= 12;
-        if (kk - 2 >= 0) QRW_LOAD(pA0, pA1, pA2, pC0, pC1, pC2);
-        QRW_STEP(qA0, qA1, qA2, qC0, qC1, qC2);
-        ps -= 12;
-      }
-      if (kk >= 0) QRW_STEP(pA0, pA1, pA2, pC0, pC1, pC2);
-#undef QRW_LOAD
-#undef QRW_STEP
-    }
+    // backward sweep x_k = v_k - N_{k+1}' x_{k+1}, k = N-2..0 (transposed read of the same column-major slots)
+    chain_sweep((unsigned)(size_t)&L.sN[(N - 2) * kSlot + offA_b0], offA_b1 * 8, offA_b2 * 8,
+                (unsigned)(size_t)&L.sX[(N - 2) * 12 + mq], (unsigned)(size_t)&L.sX[(N - 1) * 12 + mq], -kSlot * 8, -96,
+                N - 1);
     wg_sync();
     PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates
