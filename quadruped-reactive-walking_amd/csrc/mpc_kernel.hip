@@ -34,16 +34,22 @@ constexpr int kMatSz = 144;
 constexpr int kSlot = 152;  // chain-matrix slot: 144 entries + zero pad (branch-free operand loads for MFMA rows 12..15)
 constexpr int kWSz = 36;
 
-// LDS carve (doubles). Chain matrices -N_k (k = 1..N-1), exchange vector, factor scratch.
-struct MpcLds {
+// LDS carve (doubles) for NW wavefronts per instance (16 horizon steps per wavefront): chain matrices -N_k
+// (k = 1..N-1), exchange vector, neighbour-exchange buffer (NW > 1 only), factor scratch.
+template <int NW>
+struct MpcLdsT {
+  static constexpr int S = 16 * NW;
   double sPad[kSlot];  // the backward sweep's last prefetch reads one slot below sN[0]
-  double sN[(kMpcMaxN - 1) * kSlot];
-  double sX[kMpcMaxN * 12];
-  double sW[kMpcMaxN * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
-  double sOm[kMpcMaxN * 12];    // omega_D per step (factor phase)
-  double sDg[kMpcMaxN * 12];    // c*w + sigma/Dx^2 per step (factor phase)
-  double sA[kMatSz];            // Delta_{k-1}^-1
-  double sB[kMatSz];            // Delta_k (inverted in place)
+  double sN[(S - 1) * kSlot];
+  double sX[S * 12];
+  double sE[S * 12];     // step k <-> k+-1 exchange across wavefronts
+  double sW[S * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
+  double sOm[S * 12];    // omega_D per step (factor phase)
+  double sDg[S * 12];    // c*w + sigma/Dx^2 per step (factor phase)
+  double sA[kMatSz];     // Delta_{k-1}^-1
+  double sB[kMatSz];     // Delta_k (inverted in place)
+  double sRed[4];        // cross-wavefront reductions
+  unsigned long long sBal[2];
 };
 
 __device__ __forceinline__ void wg_sync() { __syncthreads(); }
@@ -69,6 +75,65 @@ __device__ __forceinline__ void cone_apply_t(const double w[5], double mu, doubl
   out[2] = -mu * (w[0] + w[1] + w[2] + w[3]) - w[4];
 }
 
+// ---- step k <-> k+1 / k-1 neighbour values. One wavefront: ds_bpermute; two wavefronts: through LDS.
+// same[t] = value of lane (k+1, j); shifted[t] = value of lane (k+1, j-2) (only meaningful for j >= 2).
+template <int NW>
+__device__ __forceinline__ void nb_next(const double v[3], double same[3], double shifted[3], double* sE, int k, int j,
+                                        int lane, bool has_next) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], lane + 4); shifted[t] = shfl(v[t], lane + 2); }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; t++) sE[k * 12 + 3 * j + t] = v[t];
+    __syncthreads();
+    const int kn = has_next ? k + 1 : k;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { same[t] = sE[kn * 12 + 3 * j + t]; shifted[t] = sE[kn * 12 + 3 * ((j + 2) & 3) + t]; }
+    __syncthreads();
+  }
+}
+// same[t] = value of lane (k-1, j); shifted[t] = value of lane (k-1, j+2) (only meaningful for j < 2).
+template <int NW>
+__device__ __forceinline__ void nb_prev(const double v[3], double same[3], double shifted[3], double* sE, int k, int j,
+                                        int lane, bool has_prev) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], lane - 4); shifted[t] = shfl(v[t], lane - 2); }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; t++) sE[k * 12 + 3 * j + t] = v[t];
+    __syncthreads();
+    const int kp = has_prev ? k - 1 : k;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { same[t] = sE[kp * 12 + 3 * j + t]; shifted[t] = sE[kp * 12 + 3 * ((j + 2) & 3) + t]; }
+    __syncthreads();
+  }
+}
+template <int NW>
+__device__ __forceinline__ double block_max(double v, double* sRed, int wv, int lane) {
+  v = wave_max(v);
+  if constexpr (NW == 1) return v;
+  else {
+    if (lane == 0) sRed[wv] = v;
+    __syncthreads();
+    const double r = fmax(sRed[0], sRed[1]);
+    __syncthreads();
+    return r;
+  }
+}
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int lane) {
+  v = wave_sum(v);
+  if constexpr (NW == 1) return v;
+  else {
+    if (lane == 0) sRed[wv] = v;
+    __syncthreads();
+    const double r = sRed[0] + sRed[1];
+    __syncthreads();
+    return r;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // One sweep of the block-bidiagonal recursion  y_s = c_s + M_s y_{s-1}  (s = 1..steps) on the FP64 matrix cores.
@@ -160,13 +225,15 @@ __device__ __forceinline__ void chain_sweep(unsigned pa, int oa1, int oa2, unsig
 
 }  // namespace
 
-__global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
-  __shared__ MpcLds L;
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
+  __shared__ MpcLdsT<NW> L;
+  constexpr int T = 64 * NW;  // threads per instance
   // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
   // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
   const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
-  const int lane = threadIdx.x;
-  const int k = lane >> 2, j = lane & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
   const bool act = k < N;
   const bool has_next = act && (k + 1 < N);
@@ -180,7 +247,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   const int offA_b0 = (mrow < 12) ? mrow * 12 + (0 + mq) : kMatSz;  // transposed read
   const int offA_b1 = (mrow < 12) ? 4 : 0;
   const int offA_b2 = (mrow < 12) ? 8 : 0;
-  for (int e = lane; e < (kMpcMaxN - 1) * (kSlot - kMatSz); e += 64)
+  for (int e = tid; e < (16 * NW - 1) * (kSlot - kMatSz); e += T)
     L.sN[(e / (kSlot - kMatSz)) * kSlot + kMatSz + e % (kSlot - kMatSz)] = 0.0;
 
   // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
@@ -200,13 +267,13 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
 
   const double* xr = a.xref + (size_t)b * 12 * (N + 1);
   const double* fs = a.fsteps + (size_t)b * a.N_gait * 12;
-  double* st = a.st + (size_t)b * kMpcStItems * 64;
+  double* st = a.st + (size_t)b * kMpcStItems * T;
   const int num_iter = a.num_iter ? a.num_iter[b] : a.num_iter_scalar;
   const bool first = (num_iter == 0);
-#define ST(item) st[(item)*64 + lane]
+#define ST(item) st[(item)*T + tid]
 
   if (!first && !a.flags[b]) {  // reference would dereference an un-setup OSQP workspace
-    if (lane == 0) {
+    if (tid == 0) {
       a.status[b] = kStatusNotSetup;
       a.iters[b] = 0;
     }
@@ -230,8 +297,16 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   const bool mynz = act && (f3[0] != 0.0 || f3[1] != 0.0 || f3[2] != 0.0);
   const unsigned long long bal = __ballot(mynz);
   int len = N;
-  for (int kk = N - 1; kk >= 0; kk--)
-    if (((bal >> (4 * kk)) & 0xFull) == 0) len = kk;
+  if constexpr (NW == 1) {
+    for (int kk = N - 1; kk >= 0; kk--)
+      if (((bal >> (4 * kk)) & 0xFull) == 0) len = kk;
+  } else {
+    if (lane == 0) L.sBal[wv] = bal;
+    __syncthreads();
+    for (int kk = N - 1; kk >= 0; kk--)
+      if (((L.sBal[kk >> 4] >> (4 * (kk & 15))) & 0xFull) == 0) len = kk;
+    __syncthreads();
+  }
   const bool in_gait = k < len;
 
   double Bang[3][3];  // B[9+r][3j+t] of step k (MPC.cpp:440)
@@ -325,11 +400,11 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   {
     int* gg = a.gait + (size_t)b * a.N_gait * 4;
     if (first)
-      for (int e = lane; e < a.N_gait * 4; e += 64) gg[e] = 0;
+      for (int e = tid; e < a.N_gait * 4; e += T) gg[e] = 0;
     __syncthreads();
     if (act && in_gait) gg[k * 4 + j] = (f3[0] == 0.0) ? 0 : 1;
     if (act && k == len && len < a.N_gait) gg[k * 4 + j] = 0;
-    if (len == N && N < a.N_gait && lane < 4) gg[N * 4 + lane] = 0;
+    if (len == N && N < a.N_gait && tid < 4) gg[N * 4 + tid] = 0;
   }
 
   // bounds of the dynamics rows (MPC.cpp:476-486): u = -g - A x0 (first block) + D vec(xref[:,1:])
@@ -362,12 +437,12 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   for (int pass = 0; pass < 10; pass++) {
     double nX[3], nF[3], nD[3], nS[3], nC[5];
     double EdL[3], EdA[3], mDf[3], mBD[3];
+    double EnV[3], En6V[3], DxpV[3], Dxp6V[3];
+    nb_next<NW>(Ed, EnV, En6V, L.sE, k, j, lane, has_next);
+    nb_prev<NW>(Dx, DxpV, Dxp6V, L.sE, k, j, lane, has_prev);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const double En = shfl(Ed[t], lane + 4);
-      const double En6 = shfl(Ed[t], lane + 2);
-      const double Dxp = shfl(Dx[t], lane - 4);
-      const double Dxp6 = shfl(Dx[t], lane - 2);
+      const double En = EnV[t], En6 = En6V[t], Dxp = DxpV[t], Dxp6 = Dxp6V[t];
       EdL[t] = quad_bcast<2>(Ed[t]);
       EdA[t] = quad_bcast<3>(Ed[t]);
       mDf[t] = quad_max(Df[t]);
@@ -421,7 +496,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
     for (int c = 0; c < 5; c++) Ec[c] *= 1.0 / sqrt(limit_scaling(nC[c]));
     // cost normalisation: c_temp = max(mean ||P cols||inf, ||q||inf -> 1 because q = 0)
-    double ct = wave_sum(act ? colsum : 0.0) * inv_n;
+    double ct = block_sum<NW>(act ? colsum : 0.0, L.sRed, wv, lane) * inv_n;
     ct = fmax(ct, 1.0);
     ct = limit_scaling(ct);
     cs *= 1.0 / ct;
@@ -452,7 +527,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   PH_DECL
   bool need_factor = true;
   int iter = 0, status = kStatusUnsolved, rho_updates = 0;
-  double pri_res = 0.0, dua_res = 0.0;
+  double pri_res = 0.0, dua_res = 0.0, last_np = 0.0, last_nd = 0.0;
   const int max_iter = 4000;
   rho = fmin(fmax(rho, kRhoMin), kRhoMax);
 
@@ -578,7 +653,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         if (kk > 0) {  // N_k = C_k Delta_{k-1}^-1, stored negated, column-major
 #pragma unroll
           for (int s = 0; s < 3; s++) {
-            const int e = lane + 64 * s;
+            const int e = tid + T * s;
             if (e < kMatSz) {
               const int i = e / 12, ip = e % 12;
               double v = -om[i] * Mprev[i * 12 + ip];
@@ -594,7 +669,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < 3; s++) {  // Delta_k = Ttilde_k - N_k C_k'
-          const int e = lane + 64 * s;
+          const int e = tid + T * s;
           if (e < kMatSz) {
             const int i = e / 12, ip = e % 12;
             double v = 0.0;
@@ -632,7 +707,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
           const double d = 1.0 / Mcur[p * 12 + p];
 #pragma unroll
           for (int s = 0; s < 3; s++) {
-            const int e = lane + 64 * s;
+            const int e = tid + T * s;
             nv[s] = 0.0;
             if (e < kMatSz) {
               const int i = e / 12, ip = e % 12;
@@ -644,7 +719,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
           wg_sync();
 #pragma unroll
           for (int s = 0; s < 3; s++) {
-            const int e = lane + 64 * s;
+            const int e = tid + T * s;
             if (e < kMatSz) Mcur[e] = nv[s];
           }
           wg_sync();
@@ -674,10 +749,11 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     for (int c = 0; c < 5; c++) wC[c] = Ec[c] * (rho * (zC[c] - rho_inv * yC[c]));
     double rX[3], rF[3], coneT[3];
     cone_apply_t(wC, mu, coneT);
+    double wnV[3], wn6V[3];
+    nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const double wn = shfl(wD[t], lane + 4);
-      const double wn6 = shfl(wD[t], lane + 2);
+      const double wn = wnV[t], wn6 = wn6V[t];
       double v = -wD[t];
       if (has_next) {
         v += wn;
@@ -706,12 +782,13 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         double v = Ph[0][c] * rF[0] + Ph[1][c] * rF[1] + Ph[2][c] * rF[2];
         g[c] = quad_sum(act ? v : 0.0);
       }
+      double gsV[3], gnV[3], gdum[3];
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const double gs = (j == 3) ? g[3 + t] : g[t];
-        const double gn = shfl(gs, lane + 4);
-        if (j >= 2) rX[t] += (has_next ? gn : 0.0) - gs;
-      }
+      for (int t = 0; t < 3; t++) gsV[t] = (j == 3) ? g[3 + t] : g[t];
+      nb_next<NW>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+        if (j >= 2) rX[t] += (has_next ? gnV[t] : 0.0) - gsV[t];
     }
     PH(2);
     // ---- 3. block-tridiagonal solve on the matrix cores
@@ -721,7 +798,8 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     }
     wg_sync();
     // forward sweep u_k = r_k - N_k u_{k-1}, k = 1..N-1 (u_0 = r_0), in place in sX
-    chain_sweep((unsigned)(size_t)&L.sN[offA_f0], offA_f1 * 8, offA_f2 * 8, (unsigned)(size_t)&L.sX[12 + mq],
+    if (wv == 0)
+      chain_sweep((unsigned)(size_t)&L.sN[offA_f0], offA_f1 * 8, offA_f2 * 8, (unsigned)(size_t)&L.sX[12 + mq],
                 (unsigned)(size_t)&L.sX[mq], kSlot * 8, 96, N - 1);
     wg_sync();
     PH(3);
@@ -745,7 +823,8 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
     wg_sync();
     PH(4);
     // backward sweep x_k = v_k - N_{k+1}' x_{k+1}, k = N-2..0 (transposed read of the same column-major slots)
-    chain_sweep((unsigned)(size_t)&L.sN[(N - 2) * kSlot + offA_b0], offA_b1 * 8, offA_b2 * 8,
+    if (wv == 0)
+      chain_sweep((unsigned)(size_t)&L.sN[(N - 2) * kSlot + offA_b0], offA_b1 * 8, offA_b2 * 8,
                 (unsigned)(size_t)&L.sX[(N - 2) * 12 + mq], (unsigned)(size_t)&L.sX[(N - 1) * 12 + mq], -kSlot * 8, -96,
                 N - 1);
     wg_sync();
@@ -885,9 +964,11 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         double eL[3], eA[3];
 #pragma unroll
         for (int t = 0; t < 3; t++) { eL[t] = quad_bcast<2>(eD[t]); eA[t] = quad_bcast<3>(eD[t]); }
+        double enV[3], en6V[3];
+        nb_next<NW>(eD, enV, en6V, L.sE, k, j, lane, has_next);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-          const double en = shfl(eD[t], lane + 4), en6 = shfl(eD[t], lane + 2);
+          const double en = enV[t], en6 = en6V[t];
           double aty = -eD[t];
           if (has_next) {
             aty += en;
@@ -907,8 +988,9 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         }
       }
       if (!act) { pres = nz = nax = dres = naty = npx = 0.0; pres_s = nz_s = nax_s = dres_s = naty_s = npx_s = 0.0; }
-      pres = wave_max(pres); nz = wave_max(nz); nax = wave_max(nax);
-      dres = wave_max(dres); naty = wave_max(naty); npx = wave_max(npx);
+      pres = block_max<NW>(pres, L.sRed, wv, lane); nz = block_max<NW>(nz, L.sRed, wv, lane);
+      nax = block_max<NW>(nax, L.sRed, wv, lane); dres = block_max<NW>(dres, L.sRed, wv, lane);
+      naty = block_max<NW>(naty, L.sRed, wv, lane); npx = block_max<NW>(npx, L.sRed, wv, lane);
       pri_res = pres;
       dua_res = cinv * dres;
       bool done = false;
@@ -916,8 +998,10 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
         status = kStatusNonCvx;
         done = true;
       } else {
-        const double eps_prim = eps_abs + eps_rel * fmax(nz, nax);
-        const double eps_dual = eps_abs + eps_rel * (cinv * fmax(naty, npx));
+        last_np = fmax(nz, nax);
+        last_nd = cinv * fmax(naty, npx);
+        const double eps_prim = eps_abs + eps_rel * last_np;
+        const double eps_dual = eps_abs + eps_rel * last_nd;
         // is_primal_infeasible / is_dual_infeasible can never fire for this QP: the cone rows have
         // l = -inf (their u'dy+ + l'dy- sum is NaN in OSQP's arithmetic) and q = 0 (q'dx = 0).
         if (pri_res < eps_prim && dua_res < eps_dual) {
@@ -927,8 +1011,9 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
       }
       if (done) break;
       if (iter % 200 == 0) {  // adapt_rho on the SCALED residuals (compute_rho_estimate)
-        pres_s = wave_max(pres_s); nz_s = wave_max(nz_s); nax_s = wave_max(nax_s);
-        dres_s = wave_max(dres_s); naty_s = wave_max(naty_s); npx_s = wave_max(npx_s);
+        pres_s = block_max<NW>(pres_s, L.sRed, wv, lane); nz_s = block_max<NW>(nz_s, L.sRed, wv, lane);
+        nax_s = block_max<NW>(nax_s, L.sRed, wv, lane); dres_s = block_max<NW>(dres_s, L.sRed, wv, lane);
+        naty_s = block_max<NW>(naty_s, L.sRed, wv, lane); npx_s = block_max<NW>(npx_s, L.sRed, wv, lane);
         const double pn = pres_s / (fmax(nz_s, nax_s) + 1e-10);
         const double dn = dres_s / (fmax(naty_s, npx_s) + 1e-10);
         double rho_new = rho * sqrt(pn / (dn + 1e-10));
@@ -943,16 +1028,15 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   PH(7);
 #ifdef QRW_PROFILE_PHASES
-  if (lane == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
+  if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
 #endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved) {
-    // max_iter reached: OSQP re-checks with 10x tolerances (check_termination(work, 1))
-    status = kStatusMaxIter;  // residuals at iter 4000 were just tested; 4000 % 25 == 0
-    {
-      // approximate check needs the norms again; recompute cheaply is not worth it: the last
-      // check's pri_res/dua_res are current, the tolerances are re-evaluated by the host if asked.
-    }
+    // max_iter reached (4000 % 25 == 0: the residuals of the last iterate were just computed): OSQP re-checks with
+    // 10x tolerances, check_termination(work, 1)
+    const bool pok = pri_res < 10.0 * eps_abs + 10.0 * eps_rel * last_np;
+    const bool dok = dua_res < 10.0 * eps_abs + 10.0 * eps_rel * last_nd;
+    status = (pok && dok) ? kStatusSolvedInaccurate : kStatusMaxIter;
   }
 
   // =========================== E. results + persistent state ===========================
@@ -985,7 +1069,7 @@ __global__ __launch_bounds__(64, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 #pragma unroll
   for (int c = 0; c < 5; c++) { ST(kStZC + c) = zC[c]; ST(kStYC + c) = yC[c]; ST(kStEC + c) = Ec[c]; }
-  if (lane == 0) {
+  if (tid == 0) {
     a.flags[b] = 1;
     a.iters[b] = iter;
     a.status[b] = status;
@@ -1028,7 +1112,8 @@ int mpc_order_launch(const int* iters, const int* status, int* order, int B, hip
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {
   if (a.N < 1 || a.N > kMpcMaxN) return -1;
-  hipLaunchKernelGGL(mpc_solve_kernel, dim3(a.B), dim3(64), 0, stream, a);
+  if (a.N <= 16) hipLaunchKernelGGL(mpc_solve_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(mpc_solve_kernel<2>, dim3(a.B), dim3(128), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

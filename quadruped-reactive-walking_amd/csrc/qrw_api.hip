@@ -93,7 +93,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   if (!cfg || !out) return fail(-1, "qrw_create: null argument");
   if (cfg->batch < 1) return fail(-1, "qrw_create: batch must be >= 1");
   if (cfg->n_steps < 1 || cfg->n_steps > qrw::kMpcMaxN)
-    return fail(-1, "qrw_create: n_steps must be in 1..16 in this build (one wavefront per instance)");
+    return fail(-1, "qrw_create: n_steps must be in 1..32 (16 horizon steps per wavefront, at most two wavefronts)");
   if (cfg->N_gait < cfg->n_steps) return fail(-1, "qrw_create: N_gait must be >= n_steps");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -113,7 +113,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
     }                                                       \
     hipMemset((ptr), 0, (bytes));                           \
   } while (0)
-  ALLOC(h->mpc_st, B * qrw::kMpcStItems * 64 * sizeof(double));
+  ALLOC(h->mpc_st, B * qrw::kMpcStItems * qrw::mpc_threads(N) * sizeof(double));
   ALLOC(h->mpc_gait, B * cfg->N_gait * 4 * sizeof(int));
   ALLOC(h->mpc_flags, B * sizeof(int));
   ALLOC(h->mpc_iters, B * sizeof(int));
@@ -151,7 +151,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
 extern "C" int64_t qrw_state_bytes(qrw_handle h) {
   if (!h) return 0;
   const int64_t B = h->cfg.batch;
-  return B * (qrw::kMpcStItems * 64 * 8 + h->cfg.N_gait * 16 + 6 * 4 + 3 * 8 + qrw::kWbcStItems * 8 + 8);
+  return B * ((int64_t)qrw::kMpcStItems * qrw::mpc_threads(h->cfg.n_steps) * 8 + h->cfg.N_gait * 16 + 6 * 4 + 3 * 8 + qrw::kWbcStItems * 8 + 8);
 }
 
 extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d_fsteps, const int32_t* d_num_iter,
@@ -201,12 +201,13 @@ extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double*
     for (int i = 0; i < Ng * 4; i++) h_gait[i] = (double)g[i];
   }
   if (h_Sgait) {
-    std::vector<double> s(3 * 64);
-    HIP_OK(hipMemcpy(s.data(), h->mpc_st + ((size_t)b * qrw::kMpcStItems + qrw::kStS) * 64, 3 * 64 * sizeof(double),
+    const int T = qrw::mpc_threads(N);
+    std::vector<double> s(3 * T);
+    HIP_OK(hipMemcpy(s.data(), h->mpc_st + ((size_t)b * qrw::kMpcStItems + qrw::kStS) * T, 3 * T * sizeof(double),
                      hipMemcpyDeviceToHost), "D2H S");
     for (int k = 0; k < N; k++)
       for (int j = 0; j < 4; j++)
-        for (int t = 0; t < 3; t++) h_Sgait[12 * k + 3 * j + t] = s[t * 64 + 4 * k + j];
+        for (int t = 0; t < 3; t++) h_Sgait[12 * k + 3 * j + t] = s[t * T + 4 * k + j];
   }
   return 0;
 }
@@ -228,11 +229,12 @@ extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h
                                  double* h_E, double* h_c) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_state: bad argument");
   const int N = h->cfg.n_steps;
-  std::vector<double> s(qrw::kMpcStItems * 64);
+  const int T = qrw::mpc_threads(N);
+  std::vector<double> s((size_t)qrw::kMpcStItems * T);
   HIP_OK(hipDeviceSynchronize(), "sync");
-  HIP_OK(hipMemcpy(s.data(), h->mpc_st + (size_t)b * qrw::kMpcStItems * 64, s.size() * sizeof(double),
+  HIP_OK(hipMemcpy(s.data(), h->mpc_st + (size_t)b * qrw::kMpcStItems * T, s.size() * sizeof(double),
                    hipMemcpyDeviceToHost), "D2H state");
-  auto at = [&](int item, int k, int j) { return s[(size_t)item * 64 + 4 * k + j]; };
+  auto at = [&](int item, int k, int j) { return s[(size_t)item * T + 4 * k + j]; };
   for (int k = 0; k < N; k++)
     for (int j = 0; j < 4; j++) {
       for (int t = 0; t < 3; t++) {
@@ -250,7 +252,7 @@ extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h
         if (h_E) h_E[r] = at(qrw::kStEC + c, k, j);
       }
     }
-  if (h_c) *h_c = s[(size_t)qrw::kStC * 64];
+  if (h_c) *h_c = s[(size_t)qrw::kStC * T];
   return 0;
 }
 

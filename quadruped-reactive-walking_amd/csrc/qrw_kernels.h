@@ -5,7 +5,8 @@
 
 namespace qrw {
 
-constexpr int kMpcMaxN = 16;  // horizon steps handled by one wavefront (lane = 4*step + foot)
+constexpr int kMpcMaxN = 32;  // horizon steps: 16 per wavefront (lane = 4*step + foot), one or two wavefronts per instance
+inline int mpc_threads(int n_steps) { return n_steps <= 16 ? 64 : 128; }
 
 constexpr int kStatusSolved = 1;
 constexpr int kStatusSolvedInaccurate = 2;
@@ -16,7 +17,7 @@ constexpr int kStatusNonCvx = -7;
 constexpr int kStatusUnsolved = -10;
 constexpr int kStatusNotSetup = -100;
 
-// MPC persistent state: st[instance][item][lane], lane = 4*step + foot (512-B coalesced rows)
+// MPC persistent state: st[instance][item][thread], thread = 4*step + foot (coalesced rows of mpc_threads(N) doubles)
 enum MpcStateItem {
   kStXX = 0,    // x: state entries X_k[3j+t]            (OSQP scaled iterate)
   kStXF = 3,    // x: force entries f_k[3j+t]

@@ -65,3 +65,4 @@ if __name__ == "__main__":
     make("control_trot_n16.npz", 16, ("trot",), 2, 5, 777000)
     make("control_mixed_n16.npz", 16, ("walk", "bounding", "pacing"), 3, 4, 778000)
     make("control_trot_n8.npz", 8, ("trot",), 2, 3, 779000)
+    make("control_mixed_n32.npz", 32, ("walk", "trot", "bounding"), 3, 3, 780000)

@@ -70,6 +70,17 @@ def test_short_horizons(oracle_mod, synth_mod, N):
     run_sequence(oracle_mod, synth_mod, 3, N, ("trot",), 4, 41000 + N)
 
 
+@pytest.mark.parametrize("N", [17, 24, 32])
+def test_long_horizons_two_wavefronts(oracle_mod, synth_mod, N):
+    """N > 16 runs two wavefronts per instance (BASELINE config 4: N = 32, mixed walk/trot/bound schedules)."""
+    eng, refs, worst = run_sequence(oracle_mod, synth_mod, 5, N, ("walk", "trot", "bounding"), 5, 43000 + N)
+    stt = eng.mpc_state(3)
+    x, z, y = refs[3].iterates()
+    assert np.allclose(stt["x"], x, rtol=1e-6, atol=1e-9) and np.allclose(stt["y"], y, rtol=1e-6, atol=1e-9)
+    gait, S = eng.mpc_gait(3)
+    assert np.array_equal(gait, refs[3].get_gait()) and np.array_equal(S, refs[3].get_Sgait())
+
+
 def test_open_loop_noisy_states(oracle_mod, synth_mod):
     run_sequence(oracle_mod, synth_mod, 6, 16, ("trot", "walk"), 6, 51000, closed_loop=False)
 
