@@ -141,14 +141,15 @@ __device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int 
 //   pc        LDS byte address of c_1[4r + lane/16] (r = 0: +0, r = 1: +32, r = 2: +64)
 //   ps        LDS byte address of y_0[lane/16] (same strides); y_s overwrites c_s in place
 //   dA, dX    byte strides between consecutive steps (matrix slot, 12-vector), signed
-// Hand-scheduled: three operand bundles {A0,A1,A2, C/D tuple} rotate; while the three dependent
+// Hand-scheduled, entirely in the accumulator file (a208..a249: LDS loads, MFMA A/B/C/D and LDS stores all take
+// AGPRs on gfx950), so the arch VGPRs stay with the compiler: three operand bundles {A0,A1,A2, C/D tuple} rotate; while the three dependent
 // v_mfma_f64_16x16x4 of step s run (64 cycles each) the result of step s-1 is stored and the operands of step
 // s+1 are fetched.  Hazards: LDS loads -> s_waitcnt at step entry; MFMA D -> next reader 19 wait states.
 // hipcc cannot produce this: with >256 live registers it selects the AGPR form of MFMA and copies the tuple
 // through v_accvgpr_* every step, and it does not model hazards of MFMAs split over asm statements.
-#define QRW_T0 "v[180:187]"
-#define QRW_T1 "v[188:195]"
-#define QRW_T2 "v[196:203]"
+#define QRW_T0 "a[208:215]"
+#define QRW_T1 "a[216:223]"
+#define QRW_T2 "a[224:231]"
 #define QRW_LOADB(A0, A1, A2, TLO, THI)                      \
   "ds_read_b64 " A0 ", %0\n\t"                               \
   "ds_read_b64 " A1 ", %1\n\t"                               \
@@ -174,58 +175,59 @@ __device__ __forceinline__ void chain_sweep(unsigned pa, int oa1, int oa2, unsig
                                             int steps) {
   unsigned pa1 = pa + oa1, pa2 = pa + oa2;
   asm volatile(
-      "v_mov_b32 v186, 0\n\tv_mov_b32 v187, 0\n\tv_mov_b32 v194, 0\n\tv_mov_b32 v195, 0\n\t"
-      "v_mov_b32 v202, 0\n\tv_mov_b32 v203, 0\n\t"
-      "ds_read2_b64 v[196:199], %4 offset1:4\n\t"
-      "ds_read_b64 v[200:201], %4 offset:64\n\t"
+      "v_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0\n\t"
+      "v_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\t"
+      "ds_read2_b64 a[224:227], %4 offset1:4\n\t"
+      "ds_read_b64 a[228:229], %4 offset:64\n\t"
       "s_cmp_lt_i32 %7, 1\n\t"
       "s_cbranch_scc1 9f\n\t"
-      QRW_LOADB("v[204:205]", "v[206:207]", "v[208:209]", "v[180:183]", "v[184:185]")
+      QRW_LOADB("a[232:233]", "a[234:235]", "a[236:237]", "a[208:211]", "a[212:213]")
       "1:\n\t"
-      QRW_STEPB(QRW_T0, "v[204:205]", "v[206:207]", "v[208:209]", "v[196:197]", "v[198:199]", "v[200:201]",
-                QRW_LOADB("v[210:211]", "v[212:213]", "v[214:215]", "v[188:191]", "v[192:193]"))
+      QRW_STEPB(QRW_T0, "a[232:233]", "a[234:235]", "a[236:237]", "a[224:225]", "a[226:227]", "a[228:229]",
+                QRW_LOADB("a[238:239]", "a[240:241]", "a[242:243]", "a[216:219]", "a[220:221]"))
       "s_sub_u32 %7, %7, 1\n\t"
       "s_cmp_eq_u32 %7, 0\n\t"
       "s_cbranch_scc1 7f\n\t"
-      QRW_STEPB(QRW_T1, "v[210:211]", "v[212:213]", "v[214:215]", "v[180:181]", "v[182:183]", "v[184:185]",
-                QRW_LOADB("v[216:217]", "v[218:219]", "v[220:221]", "v[196:199]", "v[200:201]"))
+      QRW_STEPB(QRW_T1, "a[238:239]", "a[240:241]", "a[242:243]", "a[208:209]", "a[210:211]", "a[212:213]",
+                QRW_LOADB("a[244:245]", "a[246:247]", "a[248:249]", "a[224:227]", "a[228:229]"))
       "s_sub_u32 %7, %7, 1\n\t"
       "s_cmp_eq_u32 %7, 0\n\t"
       "s_cbranch_scc1 8f\n\t"
-      QRW_STEPB(QRW_T2, "v[216:217]", "v[218:219]", "v[220:221]", "v[188:189]", "v[190:191]", "v[192:193]",
-                QRW_LOADB("v[204:205]", "v[206:207]", "v[208:209]", "v[180:183]", "v[184:185]"))
+      QRW_STEPB(QRW_T2, "a[244:245]", "a[246:247]", "a[248:249]", "a[216:217]", "a[218:219]", "a[220:221]",
+                QRW_LOADB("a[232:233]", "a[234:235]", "a[236:237]", "a[208:211]", "a[212:213]"))
       "s_sub_u32 %7, %7, 1\n\t"
       "s_cmp_eq_u32 %7, 0\n\t"
       "s_cbranch_scc0 1b\n\t"
       "9:\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, v[196:197], v[198:199] offset1:4\n\t"
-      "ds_write_b64 %4, v[200:201] offset:64\n\t"
+      "ds_write2_b64 %4, a[224:225], a[226:227] offset1:4\n\t"
+      "ds_write_b64 %4, a[228:229] offset:64\n\t"
       "s_branch 6f\n\t"
       "7:\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, v[180:181], v[182:183] offset1:4\n\t"
-      "ds_write_b64 %4, v[184:185] offset:64\n\t"
+      "ds_write2_b64 %4, a[208:209], a[210:211] offset1:4\n\t"
+      "ds_write_b64 %4, a[212:213] offset:64\n\t"
       "s_branch 6f\n\t"
       "8:\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, v[188:189], v[190:191] offset1:4\n\t"
-      "ds_write_b64 %4, v[192:193] offset:64\n\t"
+      "ds_write2_b64 %4, a[216:217], a[218:219] offset1:4\n\t"
+      "ds_write_b64 %4, a[220:221] offset:64\n\t"
       "6:\n\t"
       "s_waitcnt lgkmcnt(0)"
       : "+v"(pa), "+v"(pa1), "+v"(pa2), "+v"(pc), "+v"(ps), "+s"(dA), "+s"(dX), "+s"(steps)
       :
-      : "memory", "scc", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191",
-        "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205",
-        "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219",
-        "v220", "v221");
+      : "memory", "scc", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
+        "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233",
+        "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247",
+        "a248", "a249");
 }
 #undef QRW_LOADB
 #undef QRW_STEPB
 
 }  // namespace
 
-template <int NW>
+// FULL: N == 16 * NW, every lane owns a live horizon step (the masks on `act` fold away)
+template <int NW, bool FULL>
 __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   __shared__ MpcLdsT<NW> L;
   constexpr int T = 64 * NW;  // threads per instance
@@ -235,9 +237,14 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
-  const bool act = k < N;
+  const bool act = FULL ? true : (k < N);
   const bool has_next = act && (k + 1 < N);
   const bool has_prev = act && (k > 0);
+  // lane-constant coefficients that replace per-iteration selects (0/1 masks folded into the multipliers)
+  const double mN = has_next ? 1.0 : 0.0, mN6 = (has_next && j >= 2) ? a.dt : 0.0;
+  const double mP = has_prev ? 1.0 : 0.0, mP6 = (has_prev && j < 2) ? a.dt : 0.0;
+  const double mG = (j >= 2) ? 1.0 : 0.0, mGN = (j >= 2 && has_next) ? 1.0 : 0.0;
+  const int kp = has_prev ? k - 1 : k;
   const int mrow = lane & 15, mq = lane >> 4;  // MFMA operand coordinates
   // A-operand offsets inside a chain-matrix slot (column-major 12x12): rows 12..15 of the 16-row MFMA tile read
   // the slot's zero pad, so the loads in the sweeps are unconditional.
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 
   // =========================== B. Ruiz equilibration (OSQP scale_data) ===========================
-  double Dx[3] = {1, 1, 1}, Df[3] = {1, 1, 1}, Ed[3] = {1, 1, 1}, Es[3] = {1, 1, 1}, Ec[5] = {1, 1, 1, 1, 1};
+  double Dx0[3] = {1, 1, 1}, Df0[3] = {1, 1, 1}, Ed[3] = {1, 1, 1}, Es[3] = {1, 1, 1}, Ec[5] = {1, 1, 1, 1, 1};
   double cs = 1.0;
   double aB[3][3];
 #pragma unroll
@@ -439,25 +446,25 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     double EdL[3], EdA[3], mDf[3], mBD[3];
     double EnV[3], En6V[3], DxpV[3], Dxp6V[3];
     nb_next<NW>(Ed, EnV, En6V, L.sE, k, j, lane, has_next);
-    nb_prev<NW>(Dx, DxpV, Dxp6V, L.sE, k, j, lane, has_prev);
+    nb_prev<NW>(Dx0, DxpV, Dxp6V, L.sE, k, j, lane, has_prev);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const double En = EnV[t], En6 = En6V[t], Dxp = DxpV[t], Dxp6 = Dxp6V[t];
       EdL[t] = quad_bcast<2>(Ed[t]);
       EdA[t] = quad_bcast<3>(Ed[t]);
-      mDf[t] = quad_max(Df[t]);
-      double mb = fmax(fmax(aB[t][0] * Df[0], aB[t][1] * Df[1]), aB[t][2] * Df[2]);
+      mDf[t] = quad_max(Df0[t]);
+      double mb = fmax(fmax(aB[t][0] * Df0[0], aB[t][1] * Df0[1]), aB[t][2] * Df0[2]);
       mBD[t] = quad_max(mb);
       // column of X_k[3j+t]
-      double v = fabs(cs * wX[t] * Dx[t] * Dx[t]);
-      v = fmax(v, Ed[t] * Dx[t]);
+      double v = fabs(cs * wX[t] * Dx0[t] * Dx0[t]);
+      v = fmax(v, Ed[t] * Dx0[t]);
       if (has_next) {
-        v = fmax(v, En * Dx[t]);
-        if (j >= 2) v = fmax(v, dt * En6 * Dx[t]);
+        v = fmax(v, En * Dx0[t]);
+        if (j >= 2) v = fmax(v, dt * En6 * Dx0[t]);
       }
       nX[t] = v;
       // dynamics row (k, 3j+t)
-      double r_ = Ed[t] * Dx[t];
+      double r_ = Ed[t] * Dx0[t];
       if (has_prev) {
         r_ = fmax(r_, Ed[t] * Dxp);
         if (j < 2) r_ = fmax(r_, dt * Ed[t] * Dxp6);
@@ -468,30 +475,30 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     for (int t = 0; t < 3; t++) {
       if (j == 2) nD[t] = fmax(nD[t], Ed[t] * dtm * mDf[t]);
       if (j == 3) nD[t] = fmax(nD[t], Ed[t] * mBD[t]);
-      double v = fabs(cs * wF * Df[t] * Df[t]);
-      v = fmax(v, dtm * EdL[t] * Df[t]);
+      double v = fabs(cs * wF * Df0[t] * Df0[t]);
+      v = fmax(v, dtm * EdL[t] * Df0[t]);
 #pragma unroll
-      for (int r = 0; r < 3; r++) v = fmax(v, aB[r][t] * EdA[r] * Df[t]);
-      v = fmax(v, sfl[t] * Es[t] * Df[t]);
+      for (int r = 0; r < 3; r++) v = fmax(v, aB[r][t] * EdA[r] * Df0[t]);
+      v = fmax(v, sfl[t] * Es[t] * Df0[t]);
       nF[t] = v;
-      nS[t] = sfl[t] * Es[t] * Df[t];
+      nS[t] = sfl[t] * Es[t] * Df0[t];
     }
-    nF[0] = fmax(nF[0], fmax(Ec[0], Ec[1]) * Df[0]);
-    nF[1] = fmax(nF[1], fmax(Ec[2], Ec[3]) * Df[1]);
-    nF[2] = fmax(nF[2], fmax(fmax(fmax(mu * Ec[0], mu * Ec[1]), fmax(mu * Ec[2], mu * Ec[3])), Ec[4]) * Df[2]);
-    nC[0] = Ec[0] * fmax(Df[0], mu * Df[2]);
-    nC[1] = Ec[1] * fmax(Df[0], mu * Df[2]);
-    nC[2] = Ec[2] * fmax(Df[1], mu * Df[2]);
-    nC[3] = Ec[3] * fmax(Df[1], mu * Df[2]);
-    nC[4] = Ec[4] * Df[2];
+    nF[0] = fmax(nF[0], fmax(Ec[0], Ec[1]) * Df0[0]);
+    nF[1] = fmax(nF[1], fmax(Ec[2], Ec[3]) * Df0[1]);
+    nF[2] = fmax(nF[2], fmax(fmax(fmax(mu * Ec[0], mu * Ec[1]), fmax(mu * Ec[2], mu * Ec[3])), Ec[4]) * Df0[2]);
+    nC[0] = Ec[0] * fmax(Df0[0], mu * Df0[2]);
+    nC[1] = Ec[1] * fmax(Df0[0], mu * Df0[2]);
+    nC[2] = Ec[2] * fmax(Df0[1], mu * Df0[2]);
+    nC[3] = Ec[3] * fmax(Df0[1], mu * Df0[2]);
+    nC[4] = Ec[4] * Df0[2];
     double colsum = 0.0;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      Dx[t] *= 1.0 / sqrt(limit_scaling(nX[t]));
-      Df[t] *= 1.0 / sqrt(limit_scaling(nF[t]));
+      Dx0[t] *= 1.0 / sqrt(limit_scaling(nX[t]));
+      Df0[t] *= 1.0 / sqrt(limit_scaling(nF[t]));
       Ed[t] *= 1.0 / sqrt(limit_scaling(nD[t]));
       Es[t] *= 1.0 / sqrt(limit_scaling(nS[t]));
-      colsum += fabs(cs * wX[t] * Dx[t] * Dx[t]) + fabs(cs * wF * Df[t] * Df[t]);
+      colsum += fabs(cs * wX[t] * Dx0[t] * Dx0[t]) + fabs(cs * wF * Df0[t] * Df0[t]);
     }
 #pragma unroll
     for (int c = 0; c < 5; c++) Ec[c] *= 1.0 / sqrt(limit_scaling(nC[c]));
@@ -502,15 +509,13 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     cs *= 1.0 / ct;
   }
   const double cinv = 1.0 / cs;
-  double iDx[3], iDf[3], iEd[3], iEs[3], iEc[5];
+  double iDx[3], iDf[3];
   double uD[3], lC4;
 #pragma unroll
   for (int t = 0; t < 3; t++) {
-    iDx[t] = 1.0 / Dx[t]; iDf[t] = 1.0 / Df[t]; iEd[t] = 1.0 / Ed[t]; iEs[t] = 1.0 / Es[t];
+    iDx[t] = 1.0 / Dx0[t]; iDf[t] = 1.0 / Df0[t];
     uD[t] = Ed[t] * uD0[t];
   }
-#pragma unroll
-  for (int c = 0; c < 5; c++) iEc[c] = 1.0 / Ec[c];
   lC4 = Ec[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
 
   // factor data (per lane: 3 rows of F_k^-1, Delta_k^-1 and Phi_k = F_k^-1 Gbar_k')
@@ -754,11 +759,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const double wn = wnV[t], wn6 = wn6V[t];
-      double v = -wD[t];
-      if (has_next) {
-        v += wn;
-        if (j >= 2) v += dt * wn6;
-      }
+      const double v = mN * wn + mN6 * wn6 - wD[t];
       rX[t] = sigma * xX[t] * iDx[t] + v;
     }
     {
@@ -787,8 +788,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) gsV[t] = (j == 3) ? g[3 + t] : g[t];
       nb_next<NW>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
 #pragma unroll
-      for (int t = 0; t < 3; t++)
-        if (j >= 2) rX[t] += (has_next ? gnV[t] : 0.0) - gsV[t];
+      for (int t = 0; t < 3; t++) rX[t] += mGN * gnV[t] - mG * gsV[t];
     }
     PH(2);
     // ---- 3. block-tridiagonal solve on the matrix cores
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
       double u[12], v[3];
 #pragma unroll
-      for (int c = 0; c < 12; c++) u[c] = act ? L.sX[k * 12 + c] : 0.0;
+      for (int c = 0; c < 12; c++) u[c] = L.sX[k * 12 + c];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         double s_ = 0.0;
@@ -830,14 +830,19 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     wg_sync();
     PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates
-    double Xc[12], Xp[12];
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      Xc[c] = act ? L.sX[k * 12 + c] : 0.0;
-      Xp[c] = has_prev ? L.sX[(k - 1) * 12 + c] : 0.0;
-    }
-    double fh[3], xh[3];
+    const double cL = (j == 2) ? dtm : 0.0, cA = (j == 3) ? 1.0 : 0.0;
+    double dV[6], fh[3], xh[3], xpi[3], xpi6[3];
     {
+      const double* xc = &L.sX[k * 12];
+      const double* xp = &L.sX[kp * 12];
+#pragma unroll
+      for (int c = 0; c < 6; c++) dV[c] = xc[6 + c] - mP * xp[6 + c];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        xh[t] = xc[3 * j + t];
+        xpi[t] = xp[3 * j + t];
+        xpi6[t] = xp[3 * ((j + 2) & 3) + t];
+      }
       double rFa[12];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
@@ -850,9 +855,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int c = 0; c < 12; c++) v += Fi[t][c] * rFa[c];
 #pragma unroll
-        for (int c = 0; c < 6; c++) v -= Ph[t][c] * (Xc[6 + c] - Xp[6 + c]);
+        for (int c = 0; c < 6; c++) v -= Ph[t][c] * dV[c];
         fh[t] = act ? v : 0.0;
-        xh[t] = (j == 0) ? Xc[t] : (j == 1) ? Xc[3 + t] : (j == 2) ? Xc[6 + t] : Xc[9 + t];
       }
     }
     double zDt[3], zSt[3], zCt[5];
@@ -865,13 +869,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       }
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        double v = -xh[t];
-        const double xp_i = (j == 0) ? Xp[t] : (j == 1) ? Xp[3 + t] : (j == 2) ? Xp[6 + t] : Xp[9 + t];
-        const double xp_i6 = (j == 0) ? Xp[6 + t] : Xp[9 + t];
-        v += xp_i;
-        if (j < 2) v += dt * xp_i6;
-        if (j == 2) v += dtm * pl[t];
-        if (j == 3) v += pa[t];
+        const double v = mP * xpi[t] + mP6 * xpi6[t] + cL * pl[t] + cA * pa[t] - xh[t];
         zDt[t] = Ed[t] * v;
         zSt[t] = Es[t] * sfl[t] * fh[t];
       }
@@ -907,6 +905,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     // ---- 5. termination / adaptive rho (OSQP update_info, check_termination, adapt_rho)
     const bool check = (iter % 25 == 0);
     if (check) {
+      // inverse scalings are only needed here (every 25 iterations): recomputed instead of held in registers
+      double Dx[3], Df[3], iEd[3], iEs[3], iEc[5];
+#pragma unroll
+      for (int t = 0; t < 3; t++) { Dx[t] = 1.0 / iDx[t]; Df[t] = 1.0 / iDf[t]; iEd[t] = 1.0 / Ed[t]; iEs[t] = 1.0 / Es[t]; }
+#pragma unroll
+      for (int c = 0; c < 5; c++) iEc[c] = 1.0 / Ec[c];
       double xhX[3], xhF[3];
 #pragma unroll
       for (int t = 0; t < 3; t++) { xhX[t] = Dx[t] * xX[t]; xhF[t] = Df[t] * xF[t]; }
@@ -1045,8 +1049,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const int i = 3 * j + t;
-      const double sx = has_sol ? Dx[t] * xX[t] + xr[i * (N + 1) + k + 1] : nan("");
-      const double sf = has_sol ? Df[t] * xF[t] : nan("");
+      const double sx = has_sol ? (1.0 / iDx[t]) * xX[t] + xr[i * (N + 1) + k + 1] : nan("");
+      const double sf = has_sol ? (1.0 / iDf[t]) * xF[t] : nan("");
       a.out[(size_t)b * 24 * N + i * N + k] = sx;           // retrieve_result, MPC.cpp:573
       a.out[(size_t)b * 24 * N + (12 + i) * N + k] = sf;    // MPC.cpp:574
     }
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   for (int t = 0; t < 3; t++) {
     ST(kStXX + t) = xX[t]; ST(kStXF + t) = xF[t]; ST(kStZD + t) = zD[t];
     ST(kStYD + t) = yD[t]; ST(kStYS + t) = yS[t]; ST(kStS + t) = sfl[t];
-    ST(kStDX + t) = Dx[t]; ST(kStDF + t) = Df[t]; ST(kStED + t) = Ed[t]; ST(kStES + t) = Es[t];
+    ST(kStDX + t) = 1.0 / iDx[t]; ST(kStDF + t) = 1.0 / iDf[t]; ST(kStED + t) = Ed[t]; ST(kStES + t) = Es[t];
 #pragma unroll
     for (int r = 0; r < 3; r++) ST(kStB + r * 3 + t) = Bang[r][t];
   }
@@ -1112,8 +1116,10 @@ int mpc_order_launch(const int* iters, const int* status, int* order, int B, hip
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {
   if (a.N < 1 || a.N > kMpcMaxN) return -1;
-  if (a.N <= 16) hipLaunchKernelGGL(mpc_solve_kernel<1>, dim3(a.B), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(mpc_solve_kernel<2>, dim3(a.B), dim3(128), 0, stream, a);
+  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true>), dim3(a.B), dim3(64), 0, stream, a);
+  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false>), dim3(a.B), dim3(64), 0, stream, a);
+  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true>), dim3(a.B), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false>), dim3(a.B), dim3(128), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
