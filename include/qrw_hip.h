@@ -129,6 +129,52 @@ int qrw_fixed_feet_host(qrw_handle h, const double *h_q12, const double *h_dq12,
 /* Diagonal of the neutral-configuration CRBA base block (scripts/QP_WBC.py:89-93), constant. */
 int qrw_get_base_inertia_diag(qrw_handle h, double *h_Y6);
 
+/* ---------------- planners feeding the hot path ----------------
+ * Batched Gait + FootstepPlanner + FootTrajectoryGenerator + StatePlanner with persistent per-instance state,
+ * wired as scripts/Controller.py:119-137 wires them. The timing parameters (dt_mpc, dt_wbc, T_gait, N_gait,
+ * n_steps; T_mpc = n_steps * dt_mpc) come from the handle's qrw_config. */
+typedef struct {
+  int32_t k_mpc;            /* WBC iterations per MPC iteration (scripts/main_solo12_control.py:123)           */
+  double h_ref;             /* StatePlanner::initialize h_ref_in, FootstepPlanner::initialize h_ref_in          */
+  double shoulders[12];     /* 3x4 row-major, FootstepPlanner::initialize shouldersIn (Controller.py:131-135)    */
+  double max_height;        /* FootTrajectoryGenerator::initialize maxHeightIn (Controller.py:137 -> 0.05)       */
+  double lock_time;         /* ... lockTimeIn (0.07)                                                             */
+  double init_target[12];   /* ... targetFootstepIn, 3x4                                                         */
+  double init_foot_pos[12]; /* ... initialFootPosition, 3x4                                                      */
+} qrw_planner_config;
+
+/* Replaces Gait::initialize (src/Gait.cpp:19-36), StatePlanner::initialize (src/StatePlanner.cpp:12-19),
+ * FootstepPlanner::initialize (src/FootstepPlanner.cpp:22-49), FootTrajectoryGenerator::initialize
+ * (src/FootTrajectoryGenerator.cpp:22-38). Returns -3 where Gait::initialize throws (N_gait too small). */
+int qrw_planner_init(qrw_handle h, const qrw_planner_config *pc, void *stream);
+
+/* One control iteration of the planners, in the order of scripts/Controller.py:222-236:
+ * Gait::updateGait(k, k_mpc, q, code) (src/Gait.cpp:184-192), FootstepPlanner::updateFootsteps(k % k_mpc == 0 && k != 0,
+ * k_mpc - k % k_mpc, q, b_v, b_vref) (src/FootstepPlanner.cpp:51), FootTrajectoryGenerator::update(k, o_target)
+ * (src/FootTrajectoryGenerator.cpp:108), StatePlanner::computeReferenceStates(q, v, vref, 0) (src/StatePlanner.cpp:21).
+ *   in : d_q7 [B][7] (position, quaternion xyzw), d_hv [B][6], d_vref [B][6], d_code [B] int32 joystick codes or NULL
+ *        (code_scalar then applies; 1 pacing, 2 bounding, 3 trot, 4 static as src/Gait.cpp:194-219; 5 walk)
+ *   out: d_xref [B][12][N+1], d_fsteps [B][N_gait][12], d_gait [B][N_gait][4] (current gait), d_target [B][3][4]
+ *        (o_targetFootstep), d_feet_pva [B][3][3][4] (foot position, velocity, acceleration goals); any may be NULL */
+int qrw_planner_step(qrw_handle h, int32_t k, const double *d_q7, const double *d_hv, const double *d_vref,
+                     const int32_t *d_code, int32_t code_scalar, double *d_xref, double *d_fsteps, double *d_gait,
+                     double *d_target, double *d_feet_pva, void *stream);
+
+/* One planner method at a time with host buffers (backs the bound-class drop-ins Gait / FootstepPlanner /
+ * FootTrajectoryGenerator / StatePlanner, python/gepadd.cpp:44-181). mode is a bit set: 2 Gait::updateGait,
+ * 4 FootstepPlanner::updateFootsteps (k_footsteps, refresh), 8 FootTrajectoryGenerator::update (h_target_in or the stored
+ * target), 16 StatePlanner::computeReferenceStates (z_average), 32 only copy the requested outputs. */
+int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int32_t k_footsteps, int32_t refresh, const double *h_q7,
+                          const double *h_v6, const double *h_vref6, int32_t code, const double *h_target_in,
+                          double z_average, double *h_xref, double *h_fsteps, double *h_gait, double *h_target,
+                          double *h_feet_pva);
+
+/* Getter of planner state items of instance b (count doubles): which = 0 past gait, 1 current gait, 2 desired gait
+ * (N_gait*4 each), 3 newPhase, 4 is_static, 5 remainingTime, 6 #swing feet, 7 targetFootstep (12), 8 o_targetFootstep (12),
+ * 9/10/11 foot position/velocity/acceleration (12), 12 t0s (4), 13 t_swing (4), 14 footsteps (N_gait*12, [row][xyz][foot]),
+ * 15 currentFootstep (12), 16 q_static (7), 17 trajectory target (12). */
+int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double *h_out);
+
 /* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 has the operand layout the MPC
  * chain sweeps assume. 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
 int qrw_selftest_mfma(double *max_err);

@@ -87,6 +87,20 @@ def load(fast=False):
         "wbc_oracle_qp_iter": (C.c_int, [vp]),
         "wbc_oracle_get_feet": (None, [vp, _dp, _dp, _dp]),
         "wbc_oracle_get_k_since_contact": (None, [vp, _dp]),
+        "planner_oracle_create": (vp, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
+                                       C.c_double, C.c_double, _dp, _dp]),
+        "planner_oracle_destroy": (None, [vp]),
+        "planner_oracle_gait_update": (None, [vp, C.c_int, _dp, C.c_int]),
+        "planner_oracle_footsteps_update": (None, [vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
+        "planner_oracle_traj_update": (None, [vp, C.c_int, _dp]),
+        "planner_oracle_state_compute": (None, [vp, _dp, _dp, _dp, C.c_double]),
+        "planner_oracle_step": (None, [vp, C.c_int, _dp, _dp, _dp, C.c_int]),
+        "planner_oracle_phase_duration": (C.c_double, [vp, C.c_int, C.c_int, C.c_double]),
+        "planner_oracle_get_gaits": (None, [vp, _dp, _dp, _dp]),
+        "planner_oracle_get_flags": (None, [vp, _dp]),
+        "planner_oracle_get_xref": (None, [vp, _dp]),
+        "planner_oracle_get_footsteps": (None, [vp, _dp, _dp, _dp]),
+        "planner_oracle_get_feet": (None, [vp, _dp, _dp, _dp, _dp, _dp]),
         "mpc_oracle_run_batch": (C.c_int, [C.POINTER(vp), C.c_int, _ip, _dp, _dp, _dp, C.c_int]),
         "wbc_oracle_compute_batch": (C.c_int, [C.POINTER(vp), C.c_int] + [_dp] * 11 + [C.c_int]),
     }
@@ -461,3 +475,76 @@ class OSQP:
         D = np.ctypeslib.as_array(self._lib.oq_scaling_D(self._h), (self.n,)).copy()
         E = np.ctypeslib.as_array(self._lib.oq_scaling_E(self._h), (self.m,)).copy()
         return D, E, self._lib.oq_scaling_c(self._h)
+
+
+class Planner:
+    """Oracle counterpart of the reference planner objects (Gait, StatePlanner, FootstepPlanner,
+    FootTrajectoryGenerator; python/gepadd.cpp:44-181) wired as scripts/Controller.py:119-137 wires them."""
+
+    def __init__(self, dt_mpc=0.02, dt_wbc=0.002, T_gait=0.32, T_mpc=0.32, N_gait=20, k_mpc=10, h_ref=0.2229,
+                 shoulders=None, max_height=0.05, lock_time=0.07, init_target=None, init_foot_pos=None):
+        self._lib = load()
+        if shoulders is None:
+            shoulders = np.array([[0.1946, 0.1946, -0.1946, -0.1946], [0.14695, -0.14695, 0.14695, -0.14695],
+                                  [0.0, 0.0, 0.0, 0.0]])
+        sh = _arr(shoulders, (3, 4))
+        it = _arr(init_target if init_target is not None else sh, (3, 4))
+        ip = _arr(init_foot_pos if init_foot_pos is not None else sh, (3, 4))
+        self.N_gait, self.n_steps = int(N_gait), int(round(T_mpc / dt_mpc))
+        self._h = self._lib.planner_oracle_create(dt_mpc, dt_wbc, T_gait, T_mpc, int(N_gait), int(k_mpc), h_ref,
+                                                  _ptr(sh), max_height, lock_time, _ptr(it), _ptr(ip))
+        if not self._h:
+            raise ValueError("Sizes of matrices are too small for considered durations. Increase N_gait in config file.")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.planner_oracle_destroy(self._h)
+            self._h = None
+
+    def step(self, k, q7, h_v, vref, code=0):
+        self._lib.planner_oracle_step(self._h, int(k), _ptr(_arr(q7, (7,))), _ptr(_arr(h_v, (6,))),
+                                      _ptr(_arr(vref, (6,))), int(code))
+
+    def gait_update(self, k, q7, code):
+        self._lib.planner_oracle_gait_update(self._h, int(k), _ptr(_arr(q7, (7,))), int(code))
+
+    def footsteps_update(self, refresh, k, q7, b_v, b_vref):
+        out = np.zeros((3, 4))
+        self._lib.planner_oracle_footsteps_update(self._h, int(bool(refresh)), int(k), _ptr(_arr(q7, (7,))),
+                                                  _ptr(_arr(b_v, (6,))), _ptr(_arr(b_vref, (6,))), _ptr(out))
+        return out
+
+    def traj_update(self, k, target):
+        self._lib.planner_oracle_traj_update(self._h, int(k), _ptr(_arr(target, (3, 4))))
+
+    def state_compute(self, q7, v, vref, z_average=0.0):
+        self._lib.planner_oracle_state_compute(self._h, _ptr(_arr(q7, (7,))), _ptr(_arr(v, (6,))),
+                                               _ptr(_arr(vref, (6,))), float(z_average))
+
+    def phase_duration(self, i, j, value):
+        return self._lib.planner_oracle_phase_duration(self._h, int(i), int(j), float(value))
+
+    def gaits(self):
+        a, b, c = (np.zeros((self.N_gait, 4)) for _ in range(3))
+        self._lib.planner_oracle_get_gaits(self._h, _ptr(a), _ptr(b), _ptr(c))
+        return a, b, c
+
+    def flags(self):
+        f = np.zeros(4)
+        self._lib.planner_oracle_get_flags(self._h, _ptr(f))
+        return dict(new_phase=bool(f[0]), is_static=bool(f[1]), remaining_time=f[2], n_swing=int(f[3]))
+
+    def xref(self):
+        x = np.zeros((12, self.n_steps + 1))
+        self._lib.planner_oracle_get_xref(self._h, _ptr(x))
+        return x
+
+    def footsteps(self):
+        f, t, ot = np.zeros((self.N_gait, 12)), np.zeros((3, 4)), np.zeros((3, 4))
+        self._lib.planner_oracle_get_footsteps(self._h, _ptr(f), _ptr(t), _ptr(ot))
+        return f, t, ot
+
+    def feet(self):
+        p, v, a, t0, ts = np.zeros((3, 4)), np.zeros((3, 4)), np.zeros((3, 4)), np.zeros(4), np.zeros(4)
+        self._lib.planner_oracle_get_feet(self._h, _ptr(p), _ptr(v), _ptr(a), _ptr(t0), _ptr(ts))
+        return p, v, a, t0, ts

@@ -103,6 +103,26 @@ int wbc_oracle_qp_iter(const wbc_oracle *o);
 void wbc_oracle_get_feet(const wbc_oracle *o, double *feet_pos3x4, double *feet_err3x4, double *feet_vel3x4);
 void wbc_oracle_get_k_since_contact(const wbc_oracle *o, double *k4);
 
+/* --------- planners feeding the hot path (oracle/planner_oracle.c) --------- */
+typedef struct planner_oracle planner_oracle;
+planner_oracle *planner_oracle_create(double dt_mpc, double dt_wbc, double T_gait, double T_mpc, int N_gait, int k_mpc,
+                                      double h_ref, const double *shoulders3x4, double max_height, double lock_time,
+                                      const double *init_target3x4, const double *init_foot_pos3x4);
+void planner_oracle_destroy(planner_oracle *o);
+void planner_oracle_gait_update(planner_oracle *o, int k, const double *q7, int code);          /* Gait::updateGait */
+void planner_oracle_footsteps_update(planner_oracle *o, int refresh, int k, const double *q7, const double *b_v,
+                                     const double *b_vref, double *out_target3x4);              /* FootstepPlanner::updateFootsteps */
+void planner_oracle_traj_update(planner_oracle *o, int k, const double *target3x4);             /* FootTrajectoryGenerator::update */
+void planner_oracle_state_compute(planner_oracle *o, const double *q7, const double *v6, const double *vref6,
+                                  double z_average);                                            /* StatePlanner::computeReferenceStates */
+void planner_oracle_step(planner_oracle *o, int k, const double *q7, const double *h_v6, const double *vref6, int code);
+double planner_oracle_phase_duration(planner_oracle *o, int i, int j, double value);            /* Gait::getPhaseDuration */
+void planner_oracle_get_gaits(const planner_oracle *o, double *past, double *cur, double *des);
+void planner_oracle_get_flags(const planner_oracle *o, double *out4); /* newPhase, is_static, remainingTime, #swing feet */
+void planner_oracle_get_xref(const planner_oracle *o, double *xref);
+void planner_oracle_get_footsteps(const planner_oracle *o, double *fsteps_Ngx12, double *target3x4, double *o_target3x4);
+void planner_oracle_get_feet(const planner_oracle *o, double *pos, double *vel, double *acc, double *t0s, double *t_swing);
+
 /* batched helpers for the bench's cpu_baseline leg: `threads` OpenMP threads over instances */
 int mpc_oracle_run_batch(mpc_oracle **o, int B, const int *num_iter, const double *xref, const double *fsteps,
                          double *out, int threads);

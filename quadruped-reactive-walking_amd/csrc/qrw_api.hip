@@ -46,6 +46,10 @@ struct qrw_handle_s {
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
   double Y[6];
+  // planners
+  double* plan_st = nullptr;
+  qrw_planner_config pcfg;
+  bool plan_ready = false;
   // staging for the host-buffer entry points
   double* stage = nullptr;
   size_t stage_doubles = 0;
@@ -127,6 +131,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
   ALLOC(h->wbc_iters, B * sizeof(int));
   ALLOC(h->wbc_status, B * sizeof(int));
+  ALLOC(h->plan_st, B * (size_t)qrw::planner_state_items(cfg->N_gait) * sizeof(double));
   // staging: the largest host-API call moves M (324) + Jc (216) + ... per instance
   h->stage_doubles = B * (size_t)(12 * (N + 1) + cfg->N_gait * 12 + 24 * N + 1024);
   ALLOC(h->stage, h->stage_doubles * sizeof(double));
@@ -143,6 +148,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
+  hipFree(h->plan_st);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -423,5 +429,89 @@ extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] 
   if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
   HIP_OK(hipDeviceSynchronize(), "sync");
   HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * 10 * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
+  return 0;
+}
+
+// ------------------------------------------------------------------ planners
+static void planner_common(qrw_handle h, qrw::PlannerArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.B = h->cfg.batch; a.n_steps = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.k_mpc = h->pcfg.k_mpc;
+  a.dt_mpc = h->cfg.dt_mpc; a.dt_wbc = h->cfg.dt_wbc; a.T_gait = h->cfg.T_gait; a.T_mpc = h->cfg.dt_mpc * h->cfg.n_steps;
+  a.h_ref = h->pcfg.h_ref; a.k_feedback = 0.03; a.g = 9.81; a.L = 0.155;  // FootstepPlanner.cpp:5-7
+  a.max_height = h->pcfg.max_height; a.lock_time = h->pcfg.lock_time;
+  for (int i = 0; i < 12; i++) { a.shoulders[i] = h->pcfg.shoulders[i]; a.init_target[i] = h->pcfg.init_target[i]; a.init_pos[i] = h->pcfg.init_foot_pos[i]; }
+  a.ps = h->plan_st;
+}
+
+extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void* stream) {
+  if (!h || !pc) return fail(-1, "qrw_planner_init: null argument");
+  if (pc->k_mpc < 1) return fail(-1, "qrw_planner_init: k_mpc must be >= 1");
+  // Gait::initialize throws when the matrices are too small (src/Gait.cpp:30-31)
+  const long per = lround(h->cfg.T_gait / h->cfg.dt_mpc);
+  if (h->cfg.n_steps > h->cfg.N_gait || per > h->cfg.N_gait || h->cfg.n_steps + 1 > h->cfg.N_gait)
+    return fail(-3, "Sizes of matrices are too small for considered durations. Increase N_gait in config file.");
+  h->pcfg = *pc;
+  qrw::PlannerArgs a;
+  planner_common(h, a);
+  a.mode = qrw::kPlanInit;
+  if (qrw::planner_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_planner_init: launch failed", hipGetLastError());
+  h->plan_ready = true;
+  return 0;
+}
+
+extern "C" int qrw_planner_step(qrw_handle h, int32_t k, const double* d_q7, const double* d_hv, const double* d_vref,
+                                const int32_t* d_code, int32_t code_scalar, double* d_xref, double* d_fsteps,
+                                double* d_gait, double* d_target, double* d_feet_pva, void* stream) {
+  if (!h || !h->plan_ready) return fail(-1, "qrw_planner_step: planner not initialised");
+  if (!d_q7 || !d_hv || !d_vref) return fail(-1, "qrw_planner_step: null input");
+  qrw::PlannerArgs a;
+  planner_common(h, a);
+  a.mode = qrw::kPlanGait | qrw::kPlanFootsteps | qrw::kPlanTraj | qrw::kPlanState;
+  a.k = k;
+  a.refresh = ((k % a.k_mpc) == 0 && k != 0) ? 1 : 0;     // scripts/Controller.py:225
+  a.k_footsteps = a.k_mpc - k % a.k_mpc;                  // scripts/Controller.py:226
+  a.q7 = d_q7; a.hv = d_hv; a.vref = d_vref; a.code = d_code; a.code_scalar = code_scalar;
+  a.xref = d_xref; a.fsteps = d_fsteps; a.gait = d_gait; a.target = d_target; a.feet_pva = d_feet_pva;
+  if (qrw::planner_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_planner_step: launch failed", hipGetLastError());
+  return 0;
+}
+
+extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int32_t k_footsteps, int32_t refresh,
+                                     const double* h_q7, const double* h_v6, const double* h_vref6, int32_t code,
+                                     const double* h_target_in, double z_average, double* h_xref, double* h_fsteps,
+                                     double* h_gait, double* h_target, double* h_feet_pva) {
+  if (!h || !h->plan_ready) return fail(-1, "qrw_planner_call_host: planner not initialised");
+  const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
+  Stager s(h);
+  qrw::PlannerArgs a;
+  planner_common(h, a);
+  a.mode = mode & ~qrw::kPlanInit;
+  a.k = k; a.k_footsteps = k_footsteps; a.refresh = refresh; a.code_scalar = code; a.z_average = z_average;
+  a.q7 = h_q7 ? s.in(h_q7, B * 7) : nullptr;
+  a.hv = h_v6 ? s.in(h_v6, B * 6) : nullptr;
+  a.vref = h_vref6 ? s.in(h_vref6, B * 6) : nullptr;
+  a.target_in = h_target_in ? s.in(h_target_in, B * 12) : nullptr;
+  a.xref = h_xref ? s.out(B * 12 * (N + 1)) : nullptr;
+  a.fsteps = h_fsteps ? s.out(B * Ng * 12) : nullptr;
+  a.gait = h_gait ? s.out(B * Ng * 4) : nullptr;
+  a.target = h_target ? s.out(B * 12) : nullptr;
+  a.feet_pva = h_feet_pva ? s.out(B * 36) : nullptr;
+  if (!s.ok) return fail(-12, "qrw_planner_call_host: staging failed");
+  if (qrw::planner_launch(a, nullptr) != 0) return fail(-11, "qrw_planner_call_host: launch failed", hipGetLastError());
+  HIP_OK(hipDeviceSynchronize(), "planner sync");
+  if (!(s.back(h_xref, a.xref, B * 12 * (N + 1)) && s.back(h_fsteps, a.fsteps, B * Ng * 12) && s.back(h_gait, a.gait, B * Ng * 4) &&
+        s.back(h_target, a.target, B * 12) && s.back(h_feet_pva, a.feet_pva, B * 36)))
+    return fail(-12, "qrw_planner_call_host: D2H failed");
+  return 0;
+}
+
+extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double* h_out) {
+  if (!h || !h_out || b < 0 || b >= h->cfg.batch || count < 1) return fail(-1, "qrw_planner_get_host: bad argument");
+  const int off = qrw::planner_item_offset(h->cfg.N_gait, which);
+  if (off < 0 || off + count > qrw::planner_state_items(h->cfg.N_gait)) return fail(-1, "qrw_planner_get_host: bad item");
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  const size_t B = h->cfg.batch;
+  HIP_OK(hipMemcpy2D(h_out, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), count,
+                     hipMemcpyDeviceToHost), "D2H planner state");
   return 0;
 }

@@ -8,9 +8,9 @@ Return shapes follow eigenpy's conversion of the reference's return types: a dyn
 Eigen matrix with a single column comes back as a 1-D array (that is what lets
 scripts/QP_WBC.py:114 do `ddq_with_delta[:6, 0] += deltaddq`), other matrices as 2-D.
 
-The planner classes of the same module (StatePlanner, Gait, FootstepPlanner,
-FootTrajectoryGenerator, Params; python/gepadd.cpp:44-181,230-281) are outside the hot path
- and are not provided here.
+The planner classes of the same module (Gait, StatePlanner, FootstepPlanner, FootTrajectoryGenerator;
+python/gepadd.cpp:44-181) are provided too (SURVEY.md §8(f) ranks 1-2), backed by planner_kernel.hip;
+Params (YAML plumbing, python/gepadd.cpp:230-281) is not.
 """
 import numpy as np
 
@@ -101,16 +101,172 @@ class QPWBC:
         return {k: v[0] for k, v in s.items()}
 
 
+# ------------------------------------------------------------------------------------------------------
+# Planner classes (python/gepadd.cpp:44-181), SURVEY.md §8(f) ranks 1-2.  The reference wires them together by
+# passing the Gait object to the other initialisers (scripts/Controller.py:119-137); here the Gait object owns the
+# device-side planner state (a qrw_hip.Batch of one instance) and the other objects attach to it.
+class _PlannerCore:
+    def __init__(self, dt, T_gait, T_mpc, N_gait):
+        self.dt, self.T_gait, self.T_mpc, self.N_gait = float(dt), float(T_gait), float(T_mpc), int(N_gait)
+        self.n_steps = int(round(T_mpc / dt))
+        if self.n_steps > self.N_gait or int(round(T_gait / dt)) > self.N_gait or self.n_steps + 1 > self.N_gait:
+            # std::invalid_argument of Gait::initialize (src/Gait.cpp:30-31)
+            raise ValueError("Sizes of matrices are too small for considered durations. Increase N_gait in config file.")
+        self.cfg = dict(k_mpc=10, h_ref=0.2229, shoulders=qrw_hip.SHOULDERS.copy(), max_height=0.05, lock_time=0.07,
+                        init_target=None, init_foot_pos=None, dt_wbc=0.002)
+        self.batch = None
+        self._build()
+
+    def _build(self):
+        # (re)create the handle whenever an initialise() call changes a parameter; state restarts like the reference
+        n_steps = max(1, min(self.n_steps, 32))
+        self.batch = qrw_hip.Batch(1, n_steps=n_steps, N_gait=self.N_gait, dt_mpc=self.dt, T_gait=self.T_gait,
+                                   dt_wbc=self.cfg["dt_wbc"])
+        c = self.cfg
+        self.batch.planner_init(c["k_mpc"], c["h_ref"], c["shoulders"], c["max_height"], c["lock_time"],
+                                c["init_target"], c["init_foot_pos"])
+
+
+class Gait:
+    """Gait() + initialize(dt_in, T_gait_in, T_mpc_in, N_gait) — src/Gait.cpp, python/gepadd.cpp:93-128."""
+
+    def __init__(self):
+        self._core = None
+
+    def initialize(self, dt_in, T_gait_in, T_mpc_in, N_gait):
+        self._core = _PlannerCore(dt_in, T_gait_in, T_mpc_in, N_gait)
+
+    def _mat(self, which):
+        return self._core.batch.planner_get(which, self._core.N_gait * 4).reshape(self._core.N_gait, 4)
+
+    def getPastGait(self):
+        return self._mat(0)
+
+    def getCurrentGait(self):
+        return self._mat(1)
+
+    def getDesiredGait(self):
+        return self._mat(2)
+
+    def getIsStatic(self):
+        return bool(self._core.batch.planner_get(4, 1)[0])
+
+    def isNewPhase(self):
+        return bool(self._core.batch.planner_get(3, 1)[0])
+
+    def getQStatic(self):
+        q = np.zeros(19)
+        q[:7] = self._core.batch.planner_get(16, 7)
+        return q
+
+    def getRemainingTime(self):
+        return float(self._core.batch.planner_get(5, 1)[0])
+
+    def updateGait(self, k, k_mpc, q, joystickCode):
+        if int(k_mpc) != self._core.cfg["k_mpc"]:
+            raise ValueError("k_mpc differs from the value the planners were initialised with")
+        self._core.batch.planner_call_host(qrw_hip.PLAN_GAIT, k=int(k), q7=np.asarray(q, dtype=np.float64).ravel()[:7][None],
+                                           code=int(joystickCode), want=())
+
+    def changeGait(self, code, q):
+        # Gait::changeGait alone (src/Gait.cpp:194-219): an updateGait with k not a multiple of k_mpc never rolls
+        self._core.batch.planner_call_host(qrw_hip.PLAN_GAIT, k=1 if self._core.cfg["k_mpc"] > 1 else 0,
+                                           q7=np.asarray(q, dtype=np.float64).ravel()[:7][None], code=int(code), want=())
+        return self.getIsStatic()
+
+
+class StatePlanner:
+    """StatePlanner() + initialize(dt_in, T_mpc_in, h_ref_in) — src/StatePlanner.cpp, python/gepadd.cpp:44-62."""
+
+    def __init__(self):
+        self._b = None
+
+    def initialize(self, dt_in, T_mpc_in, h_ref_in):
+        n = int(round(T_mpc_in / dt_in))
+        self._n = n
+        self._b = qrw_hip.Batch(1, n_steps=n, N_gait=n + 4, dt_mpc=float(dt_in), T_gait=float(T_mpc_in))
+        self._b.planner_init(h_ref=float(h_ref_in))
+        self._xref = np.zeros((12, n + 1))
+
+    def computeReferenceStates(self, q, v, vref, z_average):
+        o = self._b.planner_call_host(qrw_hip.PLAN_STATE, q7=np.asarray(q, dtype=np.float64).ravel()[:7][None],
+                                      v6=np.asarray(v, dtype=np.float64).ravel()[:6][None],
+                                      vref6=np.asarray(vref, dtype=np.float64).ravel()[:6][None],
+                                      z_average=float(z_average), want=("xref",))
+        self._xref = o["xref"][0]
+
+    def getReferenceStates(self):
+        return self._xref.copy()
+
+    def getNSteps(self):
+        return self._n
+
+
+class FootstepPlanner:
+    """FootstepPlanner() + initialize(dt_in, dt_wbc_in, T_mpc_in, h_ref_in, shouldersIn, gaitIn, N_gait) —
+    src/FootstepPlanner.cpp, python/gepadd.cpp:130-160."""
+
+    def __init__(self):
+        self._core = None
+
+    def initialize(self, dt_in, dt_wbc_in, T_mpc_in, h_ref_in, shouldersIn, gaitIn, N_gait):
+        self._core = gaitIn._core
+        c = self._core.cfg
+        c["dt_wbc"], c["h_ref"], c["shoulders"] = float(dt_wbc_in), float(h_ref_in), np.asarray(shouldersIn, dtype=np.float64)[:3, :4]
+        self._core._build()
+
+    def updateFootsteps(self, refresh, k, q, b_v, b_vref):
+        o = self._core.batch.planner_call_host(qrw_hip.PLAN_FOOTSTEPS, k_footsteps=int(k), refresh=bool(refresh),
+                                               q7=np.asarray(q, dtype=np.float64).ravel()[:7][None],
+                                               v6=np.asarray(b_v, dtype=np.float64).ravel()[:6][None],
+                                               vref6=np.asarray(b_vref, dtype=np.float64).ravel()[:6][None],
+                                               want=("target",))
+        return o["target"][0]
+
+    def getFootsteps(self):
+        return self._core.batch.planner_call_host(qrw_hip.PLAN_OUTPUTS, want=("fsteps",))["fsteps"][0]
+
+    def getTargetFootsteps(self):
+        return self._core.batch.planner_get(7, 12).reshape(3, 4)
+
+
+class FootTrajectoryGenerator:
+    """FootTrajectoryGenerator() + initialize(maxHeightIn, lockTimeIn, targetFootstepIn, initialFootPosition,
+    dt_tsid_in, k_mpc_in, gaitIn) — src/FootTrajectoryGenerator.cpp, python/gepadd.cpp:162-181."""
+
+    def __init__(self):
+        self._core = None
+
+    def initialize(self, maxHeightIn, lockTimeIn, targetFootstepIn, initialFootPosition, dt_tsid_in, k_mpc_in, gaitIn):
+        self._core = gaitIn._core
+        c = self._core.cfg
+        c["max_height"], c["lock_time"], c["k_mpc"], c["dt_wbc"] = float(maxHeightIn), float(lockTimeIn), int(k_mpc_in), float(dt_tsid_in)
+        c["init_target"] = np.asarray(targetFootstepIn, dtype=np.float64)[:3, :4]
+        c["init_foot_pos"] = np.asarray(initialFootPosition, dtype=np.float64)[:3, :4]
+        self._core._build()
+
+    def update(self, k, targetFootstep):
+        self._core.batch.planner_call_host(qrw_hip.PLAN_TRAJ, k=int(k),
+                                           target_in=np.asarray(targetFootstep, dtype=np.float64)[None], want=())
+
+    def getTargetPosition(self):
+        return self._core.batch.planner_get(17, 12).reshape(3, 4)
+
+    def getFootPosition(self):
+        return self._core.batch.planner_get(9, 12).reshape(3, 4)
+
+    def getFootVelocity(self):
+        return self._core.batch.planner_get(10, 12).reshape(3, 4)
+
+    def getFootAcceleration(self):
+        return self._core.batch.planner_get(11, 12).reshape(3, 4)
+
+
 def _out_of_scope(name):
     def ctor(*a, **k):
         raise NotImplementedError(
-            "%s is a planner class outside the accelerated hot path (SURVEY.md §8(f)); use the reference's own "
-            "libquadruped_reactive_walking for it" % name)
+            "%s is outside the accelerated path (SURVEY.md §8); use the reference's own module for it" % name)
     return ctor
 
 
-StatePlanner = _out_of_scope("StatePlanner")
-Gait = _out_of_scope("Gait")
-FootstepPlanner = _out_of_scope("FootstepPlanner")
-FootTrajectoryGenerator = _out_of_scope("FootTrajectoryGenerator")
 Params = _out_of_scope("Params")

@@ -23,6 +23,15 @@ class QrwError(RuntimeError):
     pass
 
 
+class _PlannerConfig(C.Structure):
+    _fields_ = [("k_mpc", C.c_int32), ("h_ref", C.c_double), ("shoulders", C.c_double * 12), ("max_height", C.c_double),
+                ("lock_time", C.c_double), ("init_target", C.c_double * 12), ("init_foot_pos", C.c_double * 12)]
+
+
+PLAN_GAIT, PLAN_FOOTSTEPS, PLAN_TRAJ, PLAN_STATE, PLAN_OUTPUTS = 2, 4, 8, 16, 32
+SHOULDERS = np.array([[0.1946, 0.1946, -0.1946, -0.1946], [0.14695, -0.14695, 0.14695, -0.14695], [0.0, 0.0, 0.0, 0.0]])
+
+
 class _Config(C.Structure):
     _fields_ = [("batch", C.c_int32), ("n_steps", C.c_int32), ("N_gait", C.c_int32), ("device", C.c_int32),
                 ("dt_mpc", C.c_double), ("T_gait", C.c_double), ("dt_wbc", C.c_double)]
@@ -46,6 +55,11 @@ SIGNATURES = {
     "qrw_qpwbc_host": (C.c_int, [_vp] + [_dp] * 7),
     "qrw_fixed_feet_host": (C.c_int, [_vp] + [_dp] * 7),
     "qrw_get_base_inertia_diag": (C.c_int, [_vp, _dp]),
+    "qrw_planner_init": (C.c_int, [_vp, _vp, _vp]),
+    "qrw_planner_step": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qrw_planner_call_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int32, _dp,
+                                        C.c_double, _dp, _dp, _dp, _dp, _dp]),
+    "qrw_planner_get_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "qrw_selftest_mfma": (C.c_int, [_dp]),
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
@@ -227,6 +241,68 @@ class Batch:
                                         _p(_h(f_cmd, (B, 12))), _p(_h(RNEA, (B, 6))), _p(f_res), _p(ddq_res), _p(H)),
                "qrw_qpwbc_host")
         return f_res, ddq_res, H
+
+    # ------------------------------------------------ planners
+    def planner_init(self, k_mpc=10, h_ref=0.2229, shoulders=None, max_height=0.05, lock_time=0.07, init_target=None,
+                     init_foot_pos=None):
+        sh = _h(SHOULDERS if shoulders is None else shoulders, (3, 4))
+        it = _h(sh if init_target is None else init_target, (3, 4))
+        ip = _h(sh if init_foot_pos is None else init_foot_pos, (3, 4))
+        pc = _PlannerConfig()
+        pc.k_mpc, pc.h_ref, pc.max_height, pc.lock_time = int(k_mpc), float(h_ref), float(max_height), float(lock_time)
+        for i in range(12):
+            pc.shoulders[i], pc.init_target[i], pc.init_foot_pos[i] = sh.ravel()[i], it.ravel()[i], ip.ravel()[i]
+        rc = self._lib.qrw_planner_init(self._handle, C.cast(C.byref(pc), _vp), _vp(0))
+        if rc == -3:  # what Gait::initialize throws (src/Gait.cpp:30-31; std::invalid_argument -> ValueError in Python)
+            raise ValueError(self._lib.qrw_last_error().decode())
+        _check(rc, "qrw_planner_init")
+        self.k_mpc = int(k_mpc)
+
+    def planner_step(self, k, q7, hv, vref, code=0, out=None):
+        """Device API: q7 (B,7), hv (B,6), vref (B,6) CUDA float64; code int or CUDA int32 (B,). Returns dict."""
+        import torch
+
+        B, N, Ng = self.B, self.N, self.N_gait
+        if out is None:
+            dev = q7.device
+            out = dict(xref=torch.empty((B, 12, N + 1), dtype=torch.float64, device=dev),
+                       fsteps=torch.empty((B, Ng, 12), dtype=torch.float64, device=dev),
+                       gait=torch.empty((B, Ng, 4), dtype=torch.float64, device=dev),
+                       target=torch.empty((B, 3, 4), dtype=torch.float64, device=dev),
+                       feet_pva=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev))
+        cptr, cs = _vp(0), 0
+        if isinstance(code, torch.Tensor):
+            cptr = _vp(code.data_ptr())
+        else:
+            cs = int(code)
+        _check(self._lib.qrw_planner_step(self._handle, int(k), self._dev(q7, (B, 7)), self._dev(hv, (B, 6)),
+                                          self._dev(vref, (B, 6)), cptr, cs, self._dev(out["xref"], (B, 12, N + 1)),
+                                          self._dev(out["fsteps"], (B, Ng, 12)), self._dev(out["gait"], (B, Ng, 4)),
+                                          self._dev(out["target"], (B, 3, 4)), self._dev(out["feet_pva"], (B, 3, 3, 4)),
+                                          self._stream()), "qrw_planner_step")
+        return out
+
+    def planner_call_host(self, mode, k=0, k_footsteps=0, refresh=False, q7=None, v6=None, vref6=None, code=0,
+                          target_in=None, z_average=0.0, want=("xref", "fsteps", "gait", "target", "feet_pva")):
+        B, N, Ng = self.B, self.N, self.N_gait
+        o = dict(xref=np.empty((B, 12, N + 1)) if "xref" in want else None,
+                 fsteps=np.empty((B, Ng, 12)) if "fsteps" in want else None,
+                 gait=np.empty((B, Ng, 4)) if "gait" in want else None,
+                 target=np.empty((B, 3, 4)) if "target" in want else None,
+                 feet_pva=np.empty((B, 3, 3, 4)) if "feet_pva" in want else None)
+        a = [None if x is None else _h(x, shp) for x, shp in ((q7, (B, 7)), (v6, (B, 6)), (vref6, (B, 6)))]
+        t = None if target_in is None else _h(target_in, (B, 3, 4))
+        _check(self._lib.qrw_planner_call_host(self._handle, int(mode), int(k), int(k_footsteps), int(bool(refresh)),
+                                               _p(a[0]), _p(a[1]), _p(a[2]), int(code), _p(t), float(z_average),
+                                               _p(o["xref"]), _p(o["fsteps"]), _p(o["gait"]), _p(o["target"]),
+                                               _p(o["feet_pva"])), "qrw_planner_call_host")
+        return o
+
+    def planner_get(self, which, count, b=0):
+        out = np.empty(int(count))
+        _check(self._lib.qrw_planner_get_host(self._handle, int(which), int(b), int(count), _p(out)),
+               "qrw_planner_get_host")
+        return out
 
     # ------------------------------------------------ getters / diagnostics
     def mpc_gait(self, b=0):

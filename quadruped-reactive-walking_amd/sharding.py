@@ -28,10 +28,14 @@ class ResultGatherer:
     def __init__(self, b_local, width, device, dtype=torch.float64, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.out = torch.empty((self.world * b_local, width), dtype=dtype, device=device)
+        # RCCL gathers device tensors directly; other backends (gloo rehearsals on CPU or on a 1-GPU box) stage on the host
+        self.host_staged = dist.is_initialized() and dist.get_backend(group) != "nccl" and torch.device(device).type != "cpu"
+        self.out = torch.empty((self.world * b_local, width), dtype=dtype, device="cpu" if self.host_staged else device)
 
     def gather(self, local, async_op=False):
         if self.world == 1:
             self.out.copy_(local)
             return None
+        if self.host_staged:
+            local = local.cpu()
         return dist.all_gather_into_tensor(self.out, local, group=self.group, async_op=async_op)

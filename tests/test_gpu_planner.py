@@ -1,0 +1,161 @@
+"""GPU parity tests of the batched planners (planner_kernel.hip through the C ABI) vs the oracle, and of the
+fully device-resident control step planners -> MPC -> WBC."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(rng, B, k):
+    q7 = np.zeros((B, 7))
+    q7[:, 2] = 0.2229 + rng.uniform(-0.01, 0.01, B)
+    quat = np.stack([rng.uniform(-0.03, 0.03, B), rng.uniform(-0.03, 0.03, B), rng.uniform(-0.2, 0.2, B), np.ones(B)], 1)
+    q7[:, 3:] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q7[:, :2] = rng.uniform(-1, 1, (B, 2))
+    return q7
+
+
+def test_planner_step_matches_oracle(oracle_mod):
+    import qrw_hip
+
+    B, N = 9, 16
+    rng = np.random.default_rng(4)
+    eng = qrw_hip.Batch(B, N)
+    eng.planner_init()
+    refs = [oracle_mod.Planner() for _ in range(B)]
+    vref = rng.uniform(-0.5, 0.5, (B, 6)) * np.array([2, 1, 0, 0, 0, 1.4])
+    vref[0, 5] = 0.0  # exercises the vref(5) == 0 branches
+    for k in range(0, 260):
+        q7 = _inputs(rng, B, k)
+        hv = vref + rng.uniform(-0.1, 0.1, (B, 6))
+        code = np.zeros(B, np.int32)
+        if k == 57:
+            code[:] = [0, 1, 2, 3, 4, 5, 0, 2, 1]
+        if k == 140:
+            code[:] = 3
+        # per-instance codes go through the host path one value at a time: use the scalar for uniform steps
+        if len(set(code)) == 1:
+            o = eng.planner_call_host(2 | 4 | 8 | 16, k=k, k_footsteps=10 - k % 10, refresh=(k % 10 == 0 and k != 0),
+                                      q7=q7, v6=hv, vref6=vref, code=int(code[0]))
+        else:
+            import torch
+
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            od = eng.planner_step(k, t(q7), t(hv), t(vref), t(code))
+            torch.cuda.synchronize()
+            o = {kk: v.cpu().numpy() for kk, v in od.items()}
+        for b in range(B):
+            r = refs[b]
+            r.step(k, q7[b], hv[b], vref[b], int(code[b]))
+            f, tg, otg = r.footsteps()
+            pos, vel, acc, t0s, tsw = r.feet()
+            assert np.array_equal(o["gait"][b], r.gaits()[1]), (k, b)
+            assert np.allclose(o["xref"][b], r.xref(), rtol=1e-12, atol=1e-13), (k, b)
+            assert np.allclose(o["fsteps"][b], f, rtol=1e-11, atol=1e-13), (k, b)
+            assert np.allclose(o["target"][b], otg, rtol=1e-11, atol=1e-13), (k, b)
+            assert np.allclose(o["feet_pva"][b, 0], pos, rtol=1e-9, atol=1e-11), (k, b)
+            assert np.allclose(o["feet_pva"][b, 1], vel, rtol=1e-9, atol=1e-10), (k, b)
+            assert np.allclose(o["feet_pva"][b, 2], acc, rtol=1e-9, atol=1e-8), (k, b)
+        if k % 50 == 7:
+            b = 5
+            past, cur, des = refs[b].gaits()
+            Ng = 20
+            assert np.array_equal(eng.planner_get(0, Ng * 4, b).reshape(Ng, 4), past)
+            assert np.array_equal(eng.planner_get(2, Ng * 4, b).reshape(Ng, 4), des)
+            fl = refs[b].flags()
+            assert bool(eng.planner_get(3, 1, b)[0]) == fl["new_phase"] and bool(eng.planner_get(4, 1, b)[0]) == fl["is_static"]
+
+
+def test_planner_dropin_classes_match_oracle(oracle_mod):
+    """The reference-named classes called exactly as scripts/Controller.py:119-137,222-241 calls them."""
+    import libquadruped_reactive_walking as lqrw
+
+    dt_mpc, dt_wbc, T, N_gait, k_mpc, h_ref = 0.02, 0.002, 0.32, 20, 10, 0.2229
+    shoulders = np.zeros((3, 4))
+    shoulders[0, :] = [0.1946, 0.1946, -0.1946, -0.1946]
+    shoulders[1, :] = [0.14695, -0.14695, 0.14695, -0.14695]
+    fsteps_init = shoulders.copy()
+    statePlanner = lqrw.StatePlanner()
+    statePlanner.initialize(dt_mpc, T, h_ref)
+    gait = lqrw.Gait()
+    gait.initialize(dt_mpc, T, T, N_gait)
+    footstepPlanner = lqrw.FootstepPlanner()
+    footstepPlanner.initialize(dt_mpc, dt_wbc, T, h_ref, shoulders.copy(), gait, N_gait)
+    ftg = lqrw.FootTrajectoryGenerator()
+    ftg.initialize(0.05, 0.07, fsteps_init.copy(), shoulders.copy(), dt_wbc, k_mpc, gait)
+    ref = oracle_mod.Planner(dt_mpc, dt_wbc, T, T, N_gait, k_mpc, h_ref, shoulders, 0.05, 0.07, fsteps_init, shoulders)
+    with pytest.raises(ValueError):
+        lqrw.Gait().initialize(dt_mpc, T, T, 10)
+    rng = np.random.default_rng(8)
+    q = np.zeros((19, 1))
+    q[2, 0], q[6, 0] = h_ref, 1.0
+    vref = np.array([0.5, 0.1, 0, 0, 0, 0.3])
+    for k in range(0, 45):
+        h_v = (vref + rng.uniform(-0.05, 0.05, 6)).reshape(6, 1)
+        code = 2 if k == 23 else 0
+        gait.updateGait(k, k_mpc, q[0:7, 0:1], code)
+        o_target = footstepPlanner.updateFootsteps(k % k_mpc == 0 and k != 0, int(k_mpc - k % k_mpc), q[0:7, 0:1],
+                                                   h_v.copy(), vref)
+        ftg.update(k, o_target)
+        statePlanner.computeReferenceStates(q[0:7, 0:1], h_v.copy(), vref.reshape(6, 1), 0.0)
+        ref.step(k, q[:7, 0], h_v[:, 0], vref, code)
+        f, tg, otg = ref.footsteps()
+        pos, vel, acc, _, _ = ref.feet()
+        assert statePlanner.getReferenceStates().shape == (12, 17) and footstepPlanner.getFootsteps().shape == (20, 12)
+        assert np.allclose(statePlanner.getReferenceStates(), ref.xref(), rtol=1e-12, atol=1e-13)
+        assert np.allclose(footstepPlanner.getFootsteps(), f, rtol=1e-11, atol=1e-13) and np.allclose(o_target, otg, atol=1e-13)
+        assert np.array_equal(gait.getCurrentGait(), ref.gaits()[1]) and gait.getIsStatic() == ref.flags()["is_static"]
+        assert np.allclose(ftg.getFootPosition(), pos, atol=1e-11) and np.allclose(ftg.getFootVelocity(), vel, atol=1e-10)
+        assert np.allclose(ftg.getFootAcceleration(), acc, atol=1e-8)
+
+
+def test_device_resident_control_step_matches_oracle(oracle_mod):
+    """planners -> MPC -> WBC with every intermediate left in HBM, against the same pipeline on the oracle."""
+    import torch
+
+    import qrw_hip
+
+    B, N, k_mpc = 6, 16, 10
+    rng = np.random.default_rng(15)
+    eng = qrw_hip.Batch(B, N)
+    eng.planner_init(k_mpc=k_mpc)
+    planners = [oracle_mod.Planner() for _ in range(B)]
+    mpcs = [oracle_mod.MPC(0.02, N, 0.32, 20) for _ in range(B)]
+    wbcs = [oracle_mod.WbcController(0.002) for _ in range(B)]
+    vref = rng.uniform(-0.4, 0.4, (B, 6)) * np.array([2, 1, 0, 0, 0, 1.5])
+    q7 = np.zeros((B, 7))
+    q7[:, 2], q7[:, 6] = 0.2229, 1.0
+    q19 = np.zeros((B, 19))
+    q19[:, 2], q19[:, 6] = 0.2229, 1.0
+    q19[:, 7:] = [0.0, 0.7, -1.4, 0.0, 0.7, -1.4, 0.0, -0.7, 1.4, 0.0, -0.7, 1.4]
+    dq = np.zeros((B, 18))
+    dq[:, :6] = vref
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    mpc_out = None
+    x_f = [np.zeros((24, N)) for _ in range(B)]
+    for k in range(0, 32):
+        hv = vref + rng.uniform(-0.05, 0.05, (B, 6))
+        plan = eng.planner_step(k, t(q7), t(hv), t(vref), 0)
+        if k % k_mpc == 0:
+            mpc_out = eng.mpc_solve(plan["xref"], plan["fsteps"], k)
+        contacts = plan["gait"][:, 0, :].contiguous()
+        f_cmd = mpc_out[:, 12:, 0].contiguous()
+        # feet goals: foot trajectory outputs expressed relative to the base height (scripts/Controller.py:294-296, yaw = 0)
+        pg = plan["feet_pva"][:, 0].clone()
+        pg[:, 2, :] -= 0.2229
+        w = eng.wbc_compute(t(q19), t(dq), f_cmd, contacts, pg.contiguous(), plan["feet_pva"][:, 1].contiguous(),
+                            plan["feet_pva"][:, 2].contiguous())
+        torch.cuda.synchronize()
+        tau = w["tau_ff"].cpu().numpy()
+        for b in range(B):
+            planners[b].step(k, q7[b], hv[b], vref[b], 0)
+            if k % k_mpc == 0:
+                f, _, _ = planners[b].footsteps()
+                mpcs[b].run(k, planners[b].xref(), f)
+                x_f[b] = mpcs[b].get_latest_result()
+            pos, vel, acc, _, _ = planners[b].feet()
+            pgb = pos.copy()
+            pgb[2] -= 0.2229
+            wbcs[b].compute(q19[b], dq[b], x_f[b][12:, 0], planners[b].gaits()[1][0], pgb, vel, acc)
+            assert np.allclose(tau[b], wbcs[b].tau_ff, rtol=1e-4, atol=1e-6), (k, b)
+    assert np.isfinite(tau).all()
