@@ -168,6 +168,9 @@ def main():
         "input_gen_s": t_gen,
     }
 
+    if rank == 0 and world == 1:
+        out["roofline"]["traffic"] = pmc_traffic_bytes()
+        out["secondary_ratio_1_10"] = device_resident_loop(qrw_hip, sb, B, N, N_gait, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads)
     if rank == 0:
@@ -175,6 +178,58 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per mpc_solve_kernel launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE and
+    WRITE_SIZE are reported in KiB; 8-byte-per-lane accesses are uncalibrated on gfx950)."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary_bench_b4096.json")
+    try:
+        rows = json.load(open(path))
+        tot = 0.0
+        for r in rows:
+            if "mpc_solve_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                tot += r["mean"] * 1024.0
+        return tot or None
+    except Exception:
+        return None
+
+
+def device_resident_loop(qrw_hip, sb, B, N, N_gait, dev, iters=40, k_mpc=10):
+    """Secondary figure: the reference's own 1:10 MPC:WBC ratio with the planners on the device —
+    per control iteration planner step + WBC, plus one MPC solve every k_mpc iterations (scripts/Controller.py:222-303),
+    nothing leaving HBM."""
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    eng.planner_init(k_mpc=k_mpc)
+    vref = torch.from_numpy(np.ascontiguousarray(sb.vref)).to(dev)
+    q7 = torch.zeros((B, 7), dtype=torch.float64, device=dev)
+    q7[:, 2], q7[:, 6] = 0.2229, 1.0
+    d0 = sb.step(0)
+    q19 = torch.from_numpy(np.ascontiguousarray(d0["q"])).to(dev)
+    dq = torch.from_numpy(np.ascontiguousarray(d0["dq"])).to(dev)
+    plan = mpc_out = wbc_out = None
+
+    def it(k):
+        nonlocal plan, mpc_out, wbc_out
+        plan = eng.planner_step(k, q7, vref, vref, 0, out=plan)
+        if k % k_mpc == 0:
+            mpc_out = eng.mpc_solve(plan["xref"], plan["fsteps"], k, out=mpc_out)
+        pg = plan["feet_pva"][:, 0].clone()
+        pg[:, 2, :] -= 0.2229
+        wbc_out = eng.wbc_compute(q19, dq, mpc_out[:, 12:, 0].contiguous(), plan["gait"][:, 0, :].contiguous(), pg,
+                                  plan["feet_pva"][:, 1].contiguous(), plan["feet_pva"][:, 2].contiguous(), out=wbc_out)
+
+    for k in range(2 * k_mpc):
+        it(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2 * k_mpc, 2 * k_mpc + iters):
+        it(k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": B * iters / el, "unit": "control iterations/s", "iterations": iters, "k_mpc": k_mpc,
+            "ms_per_iteration": 1e3 * el / iters,
+            "what": "planners + WBC every iteration, MPC every %d-th, device-resident, batch %d" % (k_mpc, B)}
 
 
 def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):

@@ -175,6 +175,30 @@ int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int32_t k_foots
  * 15 currentFootstep (12), 16 q_static (7), 17 trajectory target (12). */
 int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double *h_out);
 
+/* ---------------- controller glue around the hot path ----------------
+ * The element-wise parts of Controller.compute (scripts/Controller.py) between planners, MPC and WBC, batched, with
+ * their per-instance state (perfect x/y/yaw integration, previous foot commands, previous q_des / v_des, error flag). */
+/* Controller.__init__ state (scripts/Controller.py:119-123,154): d_q_init12 [B][12] (or NULL = zeros) -> qdes[7:]. */
+int qrw_controller_init(qrw_handle h, const double *d_q_init12, double h_ref, void *stream);
+/* Controller.updateState (scripts/Controller.py:381-426, non-static branch): d_joy_vref [B][6], d_q_filt [B][19],
+ * d_v_filt [B][18], d_rpy [B][3] -> d_q [B][19], d_v [B][18], d_hv [B][6], d_vref [B][6] (may be NULL),
+ * d_oRh_oTh [B][12] = oRh row-major | oTh (may be NULL). */
+int qrw_controller_update_state(qrw_handle h, const double *d_joy_vref, const double *d_q_filt, const double *d_v_filt,
+                                const double *d_rpy, double *d_q, double *d_v, double *d_hv, double *d_vref,
+                                double *d_oRh_oTh, void *stream);
+/* WBC target assembly (scripts/Controller.py:258-296): d_x_f_mpc [B][24][N], d_xref [B][12][N+1], d_feet_pva [B][3][3][4]
+ * (FootTrajectoryGenerator position / velocity / acceleration), d_v [B][18] -> d_x_f_wbc [B][24] (may be NULL),
+ * d_q_wbc [B][19], d_b_v [B][18], d_f_cmd [B][12] (= x_f_wbc[12:], may be NULL), d_feet_cmd [B][3][3][4] (p, v, a commands). */
+int qrw_controller_wbc_inputs(qrw_handle h, const double *d_x_f_mpc, const double *d_xref, const double *d_feet_pva,
+                              const double *d_v, double *d_x_f_wbc, double *d_q_wbc, double *d_b_v, double *d_f_cmd,
+                              double *d_feet_cmd, void *stream);
+/* Result + security_check (scripts/Controller.py:306-310,341-365): d_tau_ff [B][12], d_qdes [B][19], d_vdes [B][18],
+ * d_q_filt [B][19], d_v_secu [B][12] -> d_result [B][5][12] = P, D, q_des, v_des, tau_ff (0.8 x), d_error_flag [B]
+ * int32 (0 ok, 1 joint position, 2 joint velocity, 3 torque; sticky, may be NULL). */
+int qrw_controller_result(qrw_handle h, const double *d_tau_ff, const double *d_qdes, const double *d_vdes,
+                          const double *d_q_filt, const double *d_v_secu, double *d_result, int32_t *d_error_flag,
+                          void *stream);
+
 /* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 has the operand layout the MPC
  * chain sweeps assume. 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
 int qrw_selftest_mfma(double *max_err);

@@ -1,0 +1,73 @@
+"""Batched, device-resident mirror of the reference's main control loop for B Solo12 instances.
+
+Mirrors `Controller.compute` of /root/reference/scripts/Controller.py:200-326 between the estimator output and the
+quantities sent to the control board: updateState -> Gait / FootstepPlanner / FootTrajectoryGenerator / StatePlanner
+-> MPC every k_mpc iterations -> WBC target assembly -> InvKin + QPWBC -> result + security_check.  Every stage is a
+HIP kernel of libqrw_hip.so working on the same handle; nothing leaves HBM.  The joystick, the state estimator, the
+PyBullet / masterboard devices and the loggers are outside the accelerated path: their outputs (reference velocity,
+filtered q / v, roll-pitch, joint velocities for the security check) are inputs here.
+"""
+import numpy as np
+
+import qrw_hip
+
+
+class Result:
+    """scripts/Controller.py:14-23 for B instances: views into one (B,5,12) device tensor."""
+
+    def __init__(self, t):
+        self.P, self.D, self.q_des, self.v_des, self.tau_ff = (t[:, i] for i in range(5))
+
+
+class Controller_batch:
+    def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
+                 h_ref=0.2229, device=0):
+        """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60)."""
+        import torch
+
+        self._torch = torch
+        self.B = int(batch)
+        self.dev = torch.device("cuda:%d" % device)
+        self.k, self.k_mpc, self.h_ref, self.dt_wbc = 0, int(k_mpc), float(h_ref), float(dt_wbc)
+        self.n_steps = int(round(T_mpc / dt_mpc))
+        self._b = qrw_hip.Batch(self.B, n_steps=self.n_steps, N_gait=int(N_gait), dt_mpc=float(dt_mpc),
+                                T_gait=float(T_gait), dt_wbc=float(dt_wbc), device=device)
+        qi = np.broadcast_to(np.asarray(q_init, dtype=np.float64).reshape(-1, 12), (self.B, 12))
+        self._b.planner_init(k_mpc=self.k_mpc, h_ref=self.h_ref)
+        self._b.controller_init(torch.from_numpy(np.ascontiguousarray(qi)).to(self.dev), self.h_ref)
+        # Default MPC result before the first solve is collected (scripts/MPC_Wrapper.py:64-71,123-126)
+        first = np.zeros((self.B, 24, self.n_steps))
+        first[:, 2, 0] = self.h_ref
+        first[:, 12:, 0] = np.array([0.0, 0.0, 8.0] * 4)
+        self._mpc_default = torch.from_numpy(first).to(self.dev)
+        self._mpc_out = None
+        self._not_first_iter = False
+        self._st = self._plan = self._wi = self._wbc = self._res = None
+        self.x_f_mpc = self._mpc_default
+
+    def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
+        """One control iteration for every instance. All arguments CUDA float64 with leading dimension B:
+        joy_v_ref (B,6), q_filt (B,19), v_filt (B,18), rpy (B,3), v_secu (B,12). Returns the Result views."""
+        b, k = self._b, self.k
+        self._st = st = b.controller_update_state(joy_v_ref, q_filt, v_filt, rpy, out=self._st)
+        self._plan = plan = b.planner_step(k, st["q"][:, :7].contiguous(), st["h_v"], st["v_ref"], joystick_code,
+                                           out=self._plan)
+        if (k % self.k_mpc) == 0:
+            self._mpc_out = b.mpc_solve(plan["xref"], plan["fsteps"], k, out=self._mpc_out)
+        if self._not_first_iter:
+            self.x_f_mpc = self._mpc_out
+        else:
+            self._not_first_iter = True
+            self.x_f_mpc = self._mpc_default
+        self._wi = wi = b.controller_wbc_inputs(self.x_f_mpc, plan["xref"], plan["feet_pva"], st["v"], out=self._wi)
+        fc = wi["feet_cmd"]
+        self._wbc = w = b.wbc_compute(wi["q_wbc"], wi["b_v"], wi["f_cmd"], plan["gait"][:, 0, :].contiguous(),
+                                      fc[:, 0], fc[:, 1], fc[:, 2], out=self._wbc)
+        self._res = b.controller_result(w["tau_ff"], w["qdes"], w["vdes"], q_filt, v_secu, out=self._res)
+        self.result = Result(self._res["result"])
+        self.error_flag = self._res["error_flag"]
+        self.k += 1
+        return self.result
+
+    def stats(self):
+        return dict(mpc=self._b.mpc_stats(), wbc=self._b.wbc_stats())

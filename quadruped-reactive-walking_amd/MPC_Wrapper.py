@@ -186,13 +186,17 @@ class MPC_Wrapper_batch:
         first[:, 12:, 0] = np.array([0.0, 0.0, 8.0] * 4)
         self._result = torch.from_numpy(first).to("cuda:%d" % device)
         self._out = None
+        self.not_first_iter = False
 
     def solve_batch(self, k, xref, fsteps):
         self._out = self._b.mpc_solve(xref, fsteps, k, out=self._out)
-        self._result = self._out
         return 0
 
     def get_latest_result_batch(self):
+        """scripts/MPC_Wrapper.py:106-126, synchronous branch: the first call returns the default forces."""
+        if self.not_first_iter:
+            return self._out if self._out is not None else self._result
+        self.not_first_iter = True
         return self._result
 
     def stats(self):

@@ -46,6 +46,8 @@ struct qrw_handle_s {
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
   double Y[6];
+  // controller glue
+  double* ctrl_st = nullptr;
   // planners
   double* plan_st = nullptr;
   qrw_planner_config pcfg;
@@ -131,6 +133,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
   ALLOC(h->wbc_iters, B * sizeof(int));
   ALLOC(h->wbc_status, B * sizeof(int));
+  ALLOC(h->ctrl_st, B * (size_t)qrw::kCtrlStItems * sizeof(double));
   ALLOC(h->plan_st, B * (size_t)qrw::planner_state_items(cfg->N_gait) * sizeof(double));
   // staging: the largest host-API call moves M (324) + Jc (216) + ... per instance
   h->stage_doubles = B * (size_t)(12 * (N + 1) + cfg->N_gait * 12 + 24 * N + 1024);
@@ -148,7 +151,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
-  hipFree(h->plan_st);
+  hipFree(h->plan_st); hipFree(h->ctrl_st);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -514,4 +517,52 @@ extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int3
   HIP_OK(hipMemcpy2D(h_out, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), count,
                      hipMemcpyDeviceToHost), "D2H planner state");
   return 0;
+}
+
+// ------------------------------------------------------------------ controller glue
+static void ctrl_common(qrw_handle h, qrw::ControllerArgs& a, int mode) {
+  memset(&a, 0, sizeof(a));
+  a.B = h->cfg.batch; a.n_steps = h->cfg.n_steps; a.mode = mode; a.dt_wbc = h->cfg.dt_wbc; a.h_ref = h->pcfg.h_ref;
+  a.cs = h->ctrl_st;
+}
+extern "C" int qrw_controller_init(qrw_handle h, const double* d_q_init12, double h_ref, void* stream) {
+  if (!h) return fail(-1, "qrw_controller_init: null handle");
+  h->pcfg.h_ref = h_ref;
+  qrw::ControllerArgs a;
+  ctrl_common(h, a, qrw::kCtrlInit);
+  a.in0 = d_q_init12;
+  return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_controller_init: launch failed", hipGetLastError()) : 0;
+}
+extern "C" int qrw_controller_update_state(qrw_handle h, const double* d_joy_vref, const double* d_q_filt,
+                                           const double* d_v_filt, const double* d_rpy, double* d_q, double* d_v,
+                                           double* d_hv, double* d_vref, double* d_oRh_oTh, void* stream) {
+  if (!h || !d_joy_vref || !d_q_filt || !d_v_filt || !d_rpy || !d_q || !d_v || !d_hv)
+    return fail(-1, "qrw_controller_update_state: null argument");
+  qrw::ControllerArgs a;
+  ctrl_common(h, a, qrw::kCtrlUpdateState);
+  a.in0 = d_joy_vref; a.in1 = d_q_filt; a.in2 = d_v_filt; a.in3 = d_rpy;
+  a.out0 = d_q; a.out1 = d_v; a.out2 = d_hv; a.out3 = d_vref; a.out4 = d_oRh_oTh;
+  return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_controller_update_state: launch failed", hipGetLastError()) : 0;
+}
+extern "C" int qrw_controller_wbc_inputs(qrw_handle h, const double* d_x_f_mpc, const double* d_xref,
+                                         const double* d_feet_pva, const double* d_v, double* d_x_f_wbc, double* d_q_wbc,
+                                         double* d_b_v, double* d_f_cmd, double* d_feet_cmd, void* stream) {
+  if (!h || !d_x_f_mpc || !d_xref || !d_feet_pva || !d_v || !d_q_wbc || !d_b_v || !d_feet_cmd)
+    return fail(-1, "qrw_controller_wbc_inputs: null argument");
+  qrw::ControllerArgs a;
+  ctrl_common(h, a, qrw::kCtrlWbcInputs);
+  a.in0 = d_x_f_mpc; a.in1 = d_xref; a.in2 = d_feet_pva; a.in3 = d_v;
+  a.out0 = d_x_f_wbc; a.out1 = d_q_wbc; a.out2 = d_b_v; a.out3 = d_f_cmd; a.out4 = d_feet_cmd;
+  return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_controller_wbc_inputs: launch failed", hipGetLastError()) : 0;
+}
+extern "C" int qrw_controller_result(qrw_handle h, const double* d_tau_ff, const double* d_qdes, const double* d_vdes,
+                                     const double* d_q_filt, const double* d_v_secu, double* d_result,
+                                     int32_t* d_error_flag, void* stream) {
+  if (!h || !d_tau_ff || !d_qdes || !d_vdes || !d_q_filt || !d_v_secu || !d_result)
+    return fail(-1, "qrw_controller_result: null argument");
+  qrw::ControllerArgs a;
+  ctrl_common(h, a, qrw::kCtrlResult);
+  a.in0 = d_tau_ff; a.in1 = d_qdes; a.in2 = d_vdes; a.in3 = d_q_filt; a.in4 = d_v_secu;
+  a.out0 = d_result; a.iout = d_error_flag;
+  return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_controller_result: launch failed", hipGetLastError()) : 0;
 }

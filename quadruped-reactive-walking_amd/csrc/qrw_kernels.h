@@ -108,6 +108,19 @@ struct PlannerArgs {
   double *xref, *fsteps, *gait, *target, *feet_pva;
 };
 int planner_state_items(int N_gait);
+
+// ---- controller glue (controller_kernel.hip)
+enum ControllerMode { kCtrlInit = 1, kCtrlUpdateState = 2, kCtrlWbcInputs = 3, kCtrlResult = 4 };
+constexpr int kCtrlStItems = 58;
+struct ControllerArgs {
+  int B, n_steps, mode;
+  double dt_wbc, h_ref;
+  const double *in0, *in1, *in2, *in3, *in4;
+  double *out0, *out1, *out2, *out3, *out4;
+  int32_t* iout;
+  double* cs;  // [kCtrlStItems][B]
+};
+int controller_launch(const ControllerArgs& a, hipStream_t stream);
 int planner_item_offset(int N_gait, int which);
 int planner_launch(const PlannerArgs& a, hipStream_t stream);
 }

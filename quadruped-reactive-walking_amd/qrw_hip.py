@@ -60,6 +60,10 @@ SIGNATURES = {
     "qrw_planner_call_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int32, _dp,
                                         C.c_double, _dp, _dp, _dp, _dp, _dp]),
     "qrw_planner_get_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "qrw_controller_init": (C.c_int, [_vp, _vp, C.c_double, _vp]),
+    "qrw_controller_update_state": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
+    "qrw_controller_wbc_inputs": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
+    "qrw_controller_result": (C.c_int, [_vp] + [_vp] * 7 + [_vp]),
     "qrw_selftest_mfma": (C.c_int, [_dp]),
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
@@ -302,6 +306,68 @@ class Batch:
         out = np.empty(int(count))
         _check(self._lib.qrw_planner_get_host(self._handle, int(which), int(b), int(count), _p(out)),
                "qrw_planner_get_host")
+        return out
+
+    # ------------------------------------------------ controller glue
+    def controller_init(self, q_init12=None, h_ref=0.2229):
+        """Controller.__init__ state (scripts/Controller.py:119-123,154). q_init12: CUDA (B,12) or None."""
+        ptr = _vp(0) if q_init12 is None else self._dev(q_init12, (self.B, 12))
+        _check(self._lib.qrw_controller_init(self._handle, ptr, float(h_ref), self._stream()), "qrw_controller_init")
+
+    def controller_update_state(self, joy_v_ref, q_filt, v_filt, rpy, out=None):
+        """Controller.updateState (scripts/Controller.py:381-426). CUDA float64 in, dict of CUDA tensors out."""
+        import torch
+
+        B = self.B
+        if out is None:
+            dev = q_filt.device
+            out = dict(q=torch.empty((B, 19), dtype=torch.float64, device=dev),
+                       v=torch.empty((B, 18), dtype=torch.float64, device=dev),
+                       h_v=torch.empty((B, 6), dtype=torch.float64, device=dev),
+                       v_ref=torch.empty((B, 6), dtype=torch.float64, device=dev),
+                       oRh_oTh=torch.empty((B, 12), dtype=torch.float64, device=dev))
+        _check(self._lib.qrw_controller_update_state(
+            self._handle, self._dev(joy_v_ref, (B, 6)), self._dev(q_filt, (B, 19)), self._dev(v_filt, (B, 18)),
+            self._dev(rpy, (B, 3)), self._dev(out["q"], (B, 19)), self._dev(out["v"], (B, 18)),
+            self._dev(out["h_v"], (B, 6)), self._dev(out["v_ref"], (B, 6)), self._dev(out["oRh_oTh"], (B, 12)),
+            self._stream()), "qrw_controller_update_state")
+        return out
+
+    def controller_wbc_inputs(self, x_f_mpc, xref, feet_pva, v, out=None):
+        """WBC target assembly (scripts/Controller.py:258-296)."""
+        import torch
+
+        B, N = self.B, self.N
+        if out is None:
+            dev = xref.device
+            out = dict(x_f_wbc=torch.empty((B, 24), dtype=torch.float64, device=dev),
+                       q_wbc=torch.empty((B, 19), dtype=torch.float64, device=dev),
+                       b_v=torch.empty((B, 18), dtype=torch.float64, device=dev),
+                       f_cmd=torch.empty((B, 12), dtype=torch.float64, device=dev),
+                       feet_cmd=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev))
+        _check(self._lib.qrw_controller_wbc_inputs(
+            self._handle, self._dev(x_f_mpc, (B, 24, N)), self._dev(xref, (B, 12, N + 1)),
+            self._dev(feet_pva, (B, 3, 3, 4)), self._dev(v, (B, 18)), self._dev(out["x_f_wbc"], (B, 24)),
+            self._dev(out["q_wbc"], (B, 19)), self._dev(out["b_v"], (B, 18)), self._dev(out["f_cmd"], (B, 12)),
+            self._dev(out["feet_cmd"], (B, 3, 3, 4)), self._stream()), "qrw_controller_wbc_inputs")
+        return out
+
+    def controller_result(self, tau_ff, qdes, vdes, q_filt, v_secu, out=None):
+        """Result + security_check (scripts/Controller.py:306-310,341-365): (B,5,12) P,D,q_des,v_des,tau_ff and flag."""
+        import torch
+
+        B = self.B
+        if out is None:
+            dev = tau_ff.device
+            out = dict(result=torch.empty((B, 5, 12), dtype=torch.float64, device=dev),
+                       error_flag=torch.empty((B,), dtype=torch.int32, device=dev))
+        if not (out["error_flag"].is_cuda and out["error_flag"].dtype == torch.int32 and out["error_flag"].is_contiguous()
+                and tuple(out["error_flag"].shape) == (B,)):
+            raise ValueError("error_flag must be a contiguous CUDA int32 tensor of shape (%d,)" % B)
+        _check(self._lib.qrw_controller_result(
+            self._handle, self._dev(tau_ff, (B, 12)), self._dev(qdes, (B, 19)), self._dev(vdes, (B, 18)),
+            self._dev(q_filt, (B, 19)), self._dev(v_secu, (B, 12)), self._dev(out["result"], (B, 5, 12)),
+            _vp(out["error_flag"].data_ptr()), self._stream()), "qrw_controller_result")
         return out
 
     # ------------------------------------------------ getters / diagnostics

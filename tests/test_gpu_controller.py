@@ -1,0 +1,132 @@
+"""GPU parity tests of the controller glue (controller_kernel.hip through the C ABI) against oracle/controller_oracle.py,
+and of the closed device-resident control loop (Controller_batch) against the chained CPU oracles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q_INIT = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])  # scripts/main_solo12_control.py:120
+
+
+def _t(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+
+
+def test_glue_stages_match_oracle():
+    import torch
+    import controller_oracle as co
+    import qrw_hip
+
+    B, N = 7, 16
+    rng = np.random.default_rng(11)
+    eng = qrw_hip.Batch(B, N)
+    qi = Q_INIT + rng.uniform(-0.05, 0.05, (B, 12))
+    eng.controller_init(_t(qi), 0.2229)
+    refs = [co.ControllerGlue(qi[b], 0.2229, 0.002) for b in range(B)]
+    for it in range(12):
+        jv = rng.uniform(-0.6, 0.6, (B, 6))
+        qf = np.zeros((B, 19))
+        qf[:, 2] = 0.2229 + rng.uniform(-0.01, 0.01, B)
+        qf[:, 7:] = qi + rng.uniform(-0.1, 0.1, (B, 12))
+        vf = rng.uniform(-0.5, 0.5, (B, 18))
+        rpy = rng.uniform(-0.2, 0.2, (B, 3))
+        st = eng.controller_update_state(_t(jv), _t(qf), _t(vf), _t(rpy))
+        xf = rng.uniform(-5, 20, (B, 24, N))
+        xr = rng.uniform(-1, 1, (B, 12, N + 1))
+        pva = rng.uniform(-0.3, 0.3, (B, 3, 3, 4))
+        wi = eng.controller_wbc_inputs(_t(xf), _t(xr), _t(pva), st["v"])
+        tau = rng.uniform(-3, 3, (B, 12))
+        qd = rng.uniform(-1, 1, (B, 19))
+        vd = rng.uniform(-1, 1, (B, 18))
+        vs = rng.uniform(-20, 20, (B, 12))
+        if it == 5:
+            tau[2, 7] = 8.5      # torque limit
+            vs[4, 3] = -51.0     # joint velocity limit
+        if it == 7:
+            qf[1, 7 + 4] = 1.45  # > 80 deg on a hip-pitch joint
+            vs[3, 0] = 60.0
+            tau[3, 1] = -9.0     # both: the torque flag wins (security_check order)
+        rs = eng.controller_result(_t(tau), _t(qd), _t(vd), _t(qf), _t(vs))
+        torch.cuda.synchronize()
+        g = {k: v.cpu().numpy() for d in (st, wi, rs) for k, v in d.items()}
+        for b in range(B):
+            r = refs[b]
+            oRh, oTh = r.update_state(jv[b], qf[b], vf[b], rpy[b])
+            assert np.allclose(g["q"][b], r.q[:, 0], rtol=1e-13, atol=1e-15), (it, b)
+            assert np.array_equal(g["v"][b], r.v[:, 0])
+            assert np.allclose(g["h_v"][b], r.h_v[:6, 0], rtol=1e-13, atol=1e-15)
+            assert np.array_equal(g["v_ref"][b], r.v_ref[:6, 0])
+            assert np.allclose(g["oRh_oTh"][b, :9].reshape(3, 3), oRh, rtol=1e-13, atol=1e-15)
+            assert np.allclose(g["oRh_oTh"][b, 9:], oTh[:, 0], rtol=1e-13, atol=1e-15)
+            xw, qw, bv = r.wbc_inputs(xf[b], xr[b], oRh, oTh, pva[b, 0], pva[b, 1], pva[b, 2])
+            assert np.allclose(g["x_f_wbc"][b], xw, rtol=1e-14, atol=0)
+            assert np.array_equal(g["f_cmd"][b], xw[12:])
+            assert np.array_equal(g["q_wbc"][b], qw[:, 0])
+            assert np.array_equal(g["b_v"][b], bv[:, 0])
+            assert np.allclose(g["feet_cmd"][b, 0], r.feet_p_cmd, rtol=1e-12, atol=1e-15)
+            assert np.allclose(g["feet_cmd"][b, 1], r.feet_v_cmd, rtol=1e-12, atol=1e-15)
+            assert np.allclose(g["feet_cmd"][b, 2], r.feet_a_cmd, rtol=1e-12, atol=1e-14)
+            P, D, q_des, v_des, t8 = r.result(tau[b], qd[b], vd[b], qf[b], vs[b])
+            assert g["error_flag"][b] == r.error_flag, (it, b)
+            for i, ref in enumerate((P, D, q_des, v_des, t8)):
+                assert np.array_equal(g["result"][b, i], ref), (it, b, i)
+    assert [r.error_flag for r in refs] == [0, 1, 3, 3, 2, 0, 0]
+
+
+def test_closed_loop_matches_chained_oracles(oracle_mod):
+    """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
+    made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state."""
+    import torch
+    import controller_oracle as co
+    from Controller import Controller_batch
+
+    B, iters = 5, 45
+    rng = np.random.default_rng(3)
+    ctl = Controller_batch(B, Q_INIT)
+    glue = [co.ControllerGlue(Q_INIT, 0.2229, 0.002) for _ in range(B)]
+    plan = [oracle_mod.Planner() for _ in range(B)]
+    mpc = [oracle_mod.MPC(0.02, 16, 0.32, 20) for _ in range(B)]
+    wbc = [oracle_mod.WbcController(0.002) for _ in range(B)]
+    first = np.zeros((24, 16))
+    first[2, 0] = 0.2229
+    first[12:, 0] = [0.0, 0.0, 8.0] * 4
+    not_first = [False] * B
+    vref = rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0])
+    qf = np.zeros((B, 19))
+    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+    vf = np.zeros((B, 18))
+    worst = 0.0
+    for k in range(iters):
+        rpy = rng.uniform(-0.02, 0.02, (B, 3))
+        vf[:, :6] = vref + rng.uniform(-0.05, 0.05, (B, 6))
+        vs = vf[:, 6:].copy()
+        res = ctl.compute(_t(vref), _t(qf), _t(vf), _t(rpy), _t(vs))
+        torch.cuda.synchronize()
+        got = ctl._res["result"].cpu().numpy()
+        flags = ctl.error_flag.cpu().numpy()
+        nq, nv = qf.copy(), vf.copy()
+        for b in range(B):
+            g = glue[b]
+            oRh, oTh = g.update_state(vref[b], qf[b], vf[b], rpy[b])
+            plan[b].step(k, g.q[:7, 0], g.h_v[:6, 0], g.v_ref[:6, 0], 0)
+            xref, (fsteps, _, _), cgait = plan[b].xref(), plan[b].footsteps(), plan[b].gaits()[1]
+            if k % 10 == 0:
+                mpc[b].run(k, xref, fsteps)
+            x_f_mpc = mpc[b].get_latest_result() if not_first[b] else first
+            not_first[b] = True
+            pos, vel, acc, _, _ = plan[b].feet()
+            xw, qw, bv = g.wbc_inputs(x_f_mpc, xref, oRh, oTh, pos, vel, acc)
+            wbc[b].compute(qw, bv, xw[12:], cgait[0, :], g.feet_p_cmd, g.feet_v_cmd, g.feet_a_cmd)
+            P, D, q_des, v_des, t8 = g.result(wbc[b].tau_ff, wbc[b].qdes, wbc[b].vdes[:, 0], qf[b], vs[b])
+            assert flags[b] == g.error_flag == 0, (k, b)
+            for i, (ref, tol) in enumerate(((P, 0), (D, 0), (q_des, 1e-4), (v_des, 1e-4), (t8, 1e-4))):
+                err = np.max(np.abs(got[b, i] - ref)) / max(1.0, np.max(np.abs(ref)))
+                worst = max(worst, err)
+                assert err <= tol, (k, b, i, err)
+            nq[b, 7:], nv[b, 6:] = q_des, v_des  # perfect tracking of the oracle's targets
+        qf, vf = nq, nv
+    st = ctl.stats()
+    assert np.all(st["mpc"]["status"] == 1)
+    print("closed loop worst relative deviation %.2e" % worst)
