@@ -188,7 +188,8 @@ int qrw_controller_update_state(qrw_handle h, const double *d_joy_vref, const do
                                 double *d_oRh_oTh, void *stream);
 /* WBC target assembly (scripts/Controller.py:258-296): d_x_f_mpc [B][24][N], d_xref [B][12][N+1], d_feet_pva [B][3][3][4]
  * (FootTrajectoryGenerator position / velocity / acceleration), d_v [B][18] -> d_x_f_wbc [B][24] (may be NULL),
- * d_q_wbc [B][19], d_b_v [B][18], d_f_cmd [B][12] (= x_f_wbc[12:], may be NULL), d_feet_cmd [B][3][3][4] (p, v, a commands). */
+ * d_q_wbc [B][19], d_b_v [B][18], d_f_cmd [B][12] (= x_f_wbc[12:], may be NULL), d_feet_cmd [3][B][3][4] (planes feet_p_cmd, feet_v_cmd, feet_a_cmd,
+ * each directly usable as the pgoals / vgoals / agoals operand of qrw_wbc_compute). */
 int qrw_controller_wbc_inputs(qrw_handle h, const double *d_x_f_mpc, const double *d_xref, const double *d_feet_pva,
                               const double *d_v, double *d_x_f_wbc, double *d_q_wbc, double *d_b_v, double *d_f_cmd,
                               double *d_feet_cmd, void *stream);

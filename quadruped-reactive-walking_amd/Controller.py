@@ -62,7 +62,7 @@ class Controller_batch:
         self._wi = wi = b.controller_wbc_inputs(self.x_f_mpc, plan["xref"], plan["feet_pva"], st["v"], out=self._wi)
         fc = wi["feet_cmd"]
         self._wbc = w = b.wbc_compute(wi["q_wbc"], wi["b_v"], wi["f_cmd"], plan["gait"][:, 0, :].contiguous(),
-                                      fc[:, 0], fc[:, 1], fc[:, 2], out=self._wbc)
+                                      fc[0], fc[1], fc[2], out=self._wbc)
         self._res = b.controller_result(w["tau_ff"], w["qdes"], w["vdes"], q_filt, v_secu, out=self._res)
         self.result = Result(self._res["result"])
         self.error_flag = self._res["error_flag"]

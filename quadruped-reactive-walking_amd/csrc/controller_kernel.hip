@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64) void controller_kernel(ControllerArgs a) {
     const double c = cos(yaw), sn = sin(yaw);
     const double w[3] = {s(cVREF + 3), s(cVREF + 4), s(cVREF + 5)};
     const double vl[3] = {s(cVREF + 0), s(cVREF + 1), s(cVREF + 2)};
-    double* fc = a.out4 + (size_t)b * 36;  // feet p | v | a commands, 3x4 each
+    double* fc = a.out4 + (size_t)b * 12;  // planes p | v | a, each [B][3][4]
+    const size_t pl = (size_t)a.B * 12;
     for (int f = 0; f < 4; f++) {
       const double pp[3] = {s(cPCMD + f), s(cPCMD + 4 + f), s(cPCMD + 8 + f)};
       const double pv[3] = {s(cVCMD + f), s(cVCMD + 4 + f), s(cVCMD + 8 + f)};
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(64) void controller_kernel(ControllerArgs a) {
       for (int r = 0; r < 3; r++) {
         const double an = ra[r] - wxwxp[r] - 2 * wxv[r];
         const double vn = (rv[r] - vl[r]) - wxp[r];
-        fc[24 + r * 4 + f] = an;
-        fc[12 + r * 4 + f] = vn;
+        fc[2 * pl + r * 4 + f] = an;
+        fc[pl + r * 4 + f] = vn;
         fc[r * 4 + f] = rp[r];
         s(cVCMD + r * 4 + f) = vn;
         s(cPCMD + r * 4 + f) = rp[r];

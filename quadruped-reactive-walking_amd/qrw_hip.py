@@ -344,12 +344,12 @@ class Batch:
                        q_wbc=torch.empty((B, 19), dtype=torch.float64, device=dev),
                        b_v=torch.empty((B, 18), dtype=torch.float64, device=dev),
                        f_cmd=torch.empty((B, 12), dtype=torch.float64, device=dev),
-                       feet_cmd=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev))
+                       feet_cmd=torch.empty((3, B, 3, 4), dtype=torch.float64, device=dev))
         _check(self._lib.qrw_controller_wbc_inputs(
             self._handle, self._dev(x_f_mpc, (B, 24, N)), self._dev(xref, (B, 12, N + 1)),
             self._dev(feet_pva, (B, 3, 3, 4)), self._dev(v, (B, 18)), self._dev(out["x_f_wbc"], (B, 24)),
             self._dev(out["q_wbc"], (B, 19)), self._dev(out["b_v"], (B, 18)), self._dev(out["f_cmd"], (B, 12)),
-            self._dev(out["feet_cmd"], (B, 3, 3, 4)), self._stream()), "qrw_controller_wbc_inputs")
+            self._dev(out["feet_cmd"], (3, B, 3, 4)), self._stream()), "qrw_controller_wbc_inputs")
         return out
 
     def controller_result(self, tau_ff, qdes, vdes, q_filt, v_secu, out=None):

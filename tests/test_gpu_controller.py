@@ -32,6 +32,8 @@ def test_glue_stages_match_oracle():
         qf[:, 7:] = qi + rng.uniform(-0.1, 0.1, (B, 12))
         vf = rng.uniform(-0.5, 0.5, (B, 18))
         rpy = rng.uniform(-0.2, 0.2, (B, 3))
+        if it == 7:
+            qf[1, 7 + 4] = 1.45  # > 80 deg on a hip-pitch joint
         st = eng.controller_update_state(_t(jv), _t(qf), _t(vf), _t(rpy))
         xf = rng.uniform(-5, 20, (B, 24, N))
         xr = rng.uniform(-1, 1, (B, 12, N + 1))
@@ -45,7 +47,6 @@ def test_glue_stages_match_oracle():
             tau[2, 7] = 8.5      # torque limit
             vs[4, 3] = -51.0     # joint velocity limit
         if it == 7:
-            qf[1, 7 + 4] = 1.45  # > 80 deg on a hip-pitch joint
             vs[3, 0] = 60.0
             tau[3, 1] = -9.0     # both: the torque flag wins (security_check order)
         rs = eng.controller_result(_t(tau), _t(qd), _t(vd), _t(qf), _t(vs))
@@ -65,9 +66,9 @@ def test_glue_stages_match_oracle():
             assert np.array_equal(g["f_cmd"][b], xw[12:])
             assert np.array_equal(g["q_wbc"][b], qw[:, 0])
             assert np.array_equal(g["b_v"][b], bv[:, 0])
-            assert np.allclose(g["feet_cmd"][b, 0], r.feet_p_cmd, rtol=1e-12, atol=1e-15)
-            assert np.allclose(g["feet_cmd"][b, 1], r.feet_v_cmd, rtol=1e-12, atol=1e-15)
-            assert np.allclose(g["feet_cmd"][b, 2], r.feet_a_cmd, rtol=1e-12, atol=1e-14)
+            assert np.allclose(g["feet_cmd"][0, b], r.feet_p_cmd, rtol=1e-12, atol=1e-15)
+            assert np.allclose(g["feet_cmd"][1, b], r.feet_v_cmd, rtol=1e-12, atol=1e-15)
+            assert np.allclose(g["feet_cmd"][2, b], r.feet_a_cmd, rtol=1e-12, atol=1e-14)
             P, D, q_des, v_des, t8 = r.result(tau[b], qd[b], vd[b], qf[b], vs[b])
             assert g["error_flag"][b] == r.error_flag, (it, b)
             for i, ref in enumerate((P, D, q_des, v_des, t8)):
