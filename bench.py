@@ -170,7 +170,7 @@ def main():
 
     if rank == 0 and world == 1:
         out["roofline"]["traffic"] = pmc_traffic_bytes()
-        out["secondary_ratio_1_10"] = device_resident_loop(qrw_hip, sb, B, N, N_gait, dev)
+        out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads)
     if rank == 0:
@@ -195,41 +195,42 @@ def pmc_traffic_bytes():
         return None
 
 
-def device_resident_loop(qrw_hip, sb, B, N, N_gait, dev, iters=40, k_mpc=10):
-    """Secondary figure: the reference's own 1:10 MPC:WBC ratio with the planners on the device —
-    per control iteration planner step + WBC, plus one MPC solve every k_mpc iterations (scripts/Controller.py:222-303),
-    nothing leaving HBM."""
-    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
-    eng.planner_init(k_mpc=k_mpc)
-    vref = torch.from_numpy(np.ascontiguousarray(sb.vref)).to(dev)
-    q7 = torch.zeros((B, 7), dtype=torch.float64, device=dev)
-    q7[:, 2], q7[:, 6] = 0.2229, 1.0
-    d0 = sb.step(0)
-    q19 = torch.from_numpy(np.ascontiguousarray(d0["q"])).to(dev)
-    dq = torch.from_numpy(np.ascontiguousarray(d0["dq"])).to(dev)
-    plan = mpc_out = wbc_out = None
+def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10):
+    """Secondary figure: the reference's own 1:10 MPC:WBC ratio, whole Controller.compute iterations
+    (scripts/Controller.py:200-326) on the device — updateState, the four planners, one MPC solve every k_mpc
+    iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM."""
+    from Controller import Controller_batch
 
-    def it(k):
-        nonlocal plan, mpc_out, wbc_out
-        plan = eng.planner_step(k, q7, vref, vref, 0, out=plan)
-        if k % k_mpc == 0:
-            mpc_out = eng.mpc_solve(plan["xref"], plan["fsteps"], k, out=mpc_out)
-        pg = plan["feet_pva"][:, 0].clone()
-        pg[:, 2, :] -= 0.2229
-        wbc_out = eng.wbc_compute(q19, dq, mpc_out[:, 12:, 0].contiguous(), plan["gait"][:, 0, :].contiguous(), pg,
-                                  plan["feet_pva"][:, 1].contiguous(), plan["feet_pva"][:, 2].contiguous(), out=wbc_out)
+    q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
+    ctl = Controller_batch(B, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=k_mpc, T_gait=0.02 * N, T_mpc=0.02 * N,
+                           N_gait=N_gait, device=dev.index or 0)
+    vref = torch.from_numpy(np.ascontiguousarray(sb.vref)).to(dev)
+    qf = torch.zeros((B, 19), dtype=torch.float64, device=dev)
+    qf[:, 2], qf[:, 6] = 0.2229, 1.0
+    qf[:, 7:] = torch.from_numpy(q_init).to(dev)
+    vf = torch.zeros((B, 18), dtype=torch.float64, device=dev)
+    vf[:, :6] = vref
+    rpy = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    vs = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+
+    def it():
+        r = ctl.compute(vref, qf, vf, rpy, vs)
+        qf[:, 7:].copy_(r.q_des)  # perfect tracking of the PD targets stands in for the robot
+        vf[:, 6:].copy_(r.v_des)
 
     for k in range(2 * k_mpc):
-        it(k)
+        it()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(2 * k_mpc, 2 * k_mpc + iters):
-        it(k)
+    for k in range(iters):
+        it()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    bad = int((ctl.error_flag != 0).sum().item())
     return {"value": B * iters / el, "unit": "control iterations/s", "iterations": iters, "k_mpc": k_mpc,
-            "ms_per_iteration": 1e3 * el / iters,
-            "what": "planners + WBC every iteration, MPC every %d-th, device-resident, batch %d" % (k_mpc, B)}
+            "ms_per_iteration": 1e3 * el / iters, "instances_in_security_stop": bad,
+            "what": "whole Controller.compute iterations (state update, planners, glue, WBC every iteration, MPC every "
+                    "%d-th), device-resident, batch %d" % (k_mpc, B)}
 
 
 def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
