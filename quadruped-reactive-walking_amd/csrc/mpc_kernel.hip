@@ -31,17 +31,16 @@ namespace qrw {
 namespace {
 
 constexpr int kMatSz = 144;
-constexpr int kSlot = 152;  // chain-matrix slot: 144 entries + zero pad (branch-free operand loads for MFMA rows 12..15)
+constexpr int kSlot = 144;  // chain-matrix slot (12x12, column-major)
 constexpr int kWSz = 36;
 
 // LDS carve (doubles) for NW wavefronts per instance (16 horizon steps per wavefront): chain matrices -N_k
 // (k = 1..N-1), exchange vector, neighbour-exchange buffer (NW > 1 only), factor scratch.
 template <int NW>
-struct MpcLdsT {
+struct alignas(16) MpcLdsT {
   static constexpr int S = 16 * NW;
-  double sPad[kSlot];  // the backward sweep's last prefetch reads one slot below sN[0]
-  double sN[(S - 1) * kSlot];
-  double sX[S * 12];
+  double sN[S * kSlot];      // S-1 chain matrices (+1 slot only ever read by the idle chain's discarded step)
+  double sX[(S + 2) * 12];   // step k at chain_pos(k); position N is a zero vector, N+1 padding for the idle step
   double sE[S * 12];     // step k <-> k+-1 exchange across wavefronts
   double sW[S * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
   double sOm[S * 12];    // omega_D per step (factor phase)
@@ -136,93 +135,107 @@ __device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One sweep of the block-bidiagonal recursion  y_s = c_s + M_s y_{s-1}  (s = 1..steps) on the FP64 matrix cores.
-//   pa        LDS byte address of this lane's A-operand entry of M_1, chunk 0 (chunks 1,2 at +oa1,+oa2)
-//   pc        LDS byte address of c_1[4r + lane/16] (r = 0: +0, r = 1: +32, r = 2: +64)
-//   ps        LDS byte address of y_0[lane/16] (same strides); y_s overwrites c_s in place
-//   dA, dX    byte strides between consecutive steps (matrix slot, 12-vector), signed
-// Hand-scheduled, entirely in the accumulator file (a208..a249: LDS loads, MFMA A/B/C/D and LDS stores all take
-// AGPRs on gfx950), so the arch VGPRs stay with the compiler: three operand bundles {A0,A1,A2, C/D tuple} rotate; while the three dependent
-// v_mfma_f64_16x16x4 of step s run (64 cycles each) the result of step s-1 is stored and the operands of step
-// s+1 are fetched.  Hazards: LDS loads -> s_waitcnt at step entry; MFMA D -> next reader 19 wait states.
-// hipcc cannot produce this: with >256 live registers it selects the AGPR form of MFMA and copies the tuple
-// through v_accvgpr_* every step, and it does not model hazards of MFMAs split over asm statements.
-#define QRW_T0 "a[208:215]"
-#define QRW_T1 "a[216:223]"
-#define QRW_T2 "a[224:231]"
-#define QRW_LOADB(A0, A1, A2, TLO, THI)                      \
-  "ds_read_b64 " A0 ", %0\n\t"                               \
-  "ds_read_b64 " A1 ", %1\n\t"                               \
-  "ds_read_b64 " A2 ", %2\n\t"                               \
-  "ds_read2_b64 " TLO ", %3 offset1:4\n\t"                   \
-  "ds_read_b64 " THI ", %3 offset:64\n\t"                    \
-  "v_add_u32 %0, %5, %0\n\t"                                 \
-  "v_add_u32 %1, %5, %1\n\t"                                 \
-  "v_add_u32 %2, %5, %2\n\t"                                 \
-  "v_add_u32 %3, %6, %3\n\t"
-#define QRW_STEPB(TC, A0, A1, A2, P01, P23, P45, LOADNEXT)   \
-  "s_waitcnt lgkmcnt(0)\n\t"                                 \
-  "v_mfma_f64_16x16x4_f64 " TC ", " A0 ", " P01 ", " TC "\n\t" \
-  "ds_write2_b64 %4, " P01 ", " P23 " offset1:4\n\t"         \
-  "ds_write_b64 %4, " P45 " offset:64\n\t"                   \
-  "v_add_u32 %4, %6, %4\n\t"                                 \
-  "v_mfma_f64_16x16x4_f64 " TC ", " A1 ", " P23 ", " TC "\n\t" \
-  LOADNEXT                                                   \
-  "v_mfma_f64_16x16x4_f64 " TC ", " A2 ", " P45 ", " TC "\n\t" \
-  "s_nop 15\n\t"                                             \
-  "s_nop 2\n\t"
-__device__ __forceinline__ void chain_sweep(unsigned pa, int oa1, int oa2, unsigned pc, unsigned ps, int dA, int dX,
-                                            int steps) {
-  unsigned pa1 = pa + oa1, pa2 = pa + oa2;
-  asm volatile(
-      "v_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0\n\t"
-      "v_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\t"
-      "ds_read2_b64 a[224:227], %4 offset1:4\n\t"
-      "ds_read_b64 a[228:229], %4 offset:64\n\t"
-      "s_cmp_lt_i32 %7, 1\n\t"
-      "s_cbranch_scc1 9f\n\t"
-      QRW_LOADB("a[232:233]", "a[234:235]", "a[236:237]", "a[208:211]", "a[212:213]")
-      "1:\n\t"
-      QRW_STEPB(QRW_T0, "a[232:233]", "a[234:235]", "a[236:237]", "a[224:225]", "a[226:227]", "a[228:229]",
-                QRW_LOADB("a[238:239]", "a[240:241]", "a[242:243]", "a[216:219]", "a[220:221]"))
-      "s_sub_u32 %7, %7, 1\n\t"
-      "s_cmp_eq_u32 %7, 0\n\t"
-      "s_cbranch_scc1 7f\n\t"
-      QRW_STEPB(QRW_T1, "a[238:239]", "a[240:241]", "a[242:243]", "a[208:209]", "a[210:211]", "a[212:213]",
-                QRW_LOADB("a[244:245]", "a[246:247]", "a[248:249]", "a[224:227]", "a[228:229]"))
-      "s_sub_u32 %7, %7, 1\n\t"
-      "s_cmp_eq_u32 %7, 0\n\t"
-      "s_cbranch_scc1 8f\n\t"
-      QRW_STEPB(QRW_T2, "a[244:245]", "a[246:247]", "a[248:249]", "a[216:217]", "a[218:219]", "a[220:221]",
-                QRW_LOADB("a[232:233]", "a[234:235]", "a[236:237]", "a[208:211]", "a[212:213]"))
-      "s_sub_u32 %7, %7, 1\n\t"
-      "s_cmp_eq_u32 %7, 0\n\t"
-      "s_cbranch_scc0 1b\n\t"
-      "9:\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, a[224:225], a[226:227] offset1:4\n\t"
-      "ds_write_b64 %4, a[228:229] offset:64\n\t"
-      "s_branch 6f\n\t"
-      "7:\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, a[208:209], a[210:211] offset1:4\n\t"
-      "ds_write_b64 %4, a[212:213] offset:64\n\t"
-      "s_branch 6f\n\t"
-      "8:\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "ds_write2_b64 %4, a[216:217], a[218:219] offset1:4\n\t"
-      "ds_write_b64 %4, a[220:221] offset:64\n\t"
-      "6:\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "+v"(pa), "+v"(pa1), "+v"(pa2), "+v"(pc), "+v"(ps), "+s"(dA), "+s"(dX), "+s"(steps)
-      :
-      : "memory", "scc", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219",
-        "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233",
-        "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247",
-        "a248", "a249");
+// 12x12 row-times-vector step on the FP64 VALU: returns r + sum_c m[c] * x(lane c of this 16-lane row).
+// v_fmac_f64 is a VOP2 on gfx950 and its DPP form takes row_newbcast (the only DPP control FP64 ops accept), so the
+// broadcast of the 12 source entries costs no extra instruction.  Two accumulators hide the FMA latency.
+// One asm statement: the compiler does not model the "VALU write -> DPP read" hazard inside inline asm, hence the
+// leading s_nop 1 (x is usually produced by the instruction just before).
+__device__ __forceinline__ double dpp_step12(double r, double x, const double (&m)[12]) {
+  double a0 = r, a1 = 0.0;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a0), "+v"(a1)
+      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
+        "v"(m[9]), "v"(m[10]), "v"(m[11]));
+  return a0 + a1;
 }
-#undef QRW_LOADB
-#undef QRW_STEPB
+
+// Twisted (two-ended) block LDL' of the block-tridiagonal state system: chain A eliminates steps 0..m-1 upwards,
+// chain B steps N-1..m+1 downwards, both meet in the root step m = N/2.  Chain A runs in DPP row 0 (lanes 0..11
+// hold vector entries 0..11 and one matrix row each), chain B in row 1, in the same instruction stream; rows 2,3
+// shadow rows 0,1 and store nothing.  Storage is arranged so that both chains walk LDS in the same direction with
+// the same stride (every access is one per-lane base register plus an immediate offset):
+//   matrices (negated, column-major, entry (i,c) at c*12+i):
+//     slot s < m : -N_{s+1},        N_k  = C_k Delta_{k-1}^-1        (k = 1..m)
+//     slot s >= m: -Nt_{N-2-(s-m)}, Nt_k = C_{k+1}' Delta_{k+1}^-1   (k = m..N-2; slot m + N-2-k)
+//   vectors: step k lives at position pos(k) = k (k <= m), m + N - k (k > m); position N holds zeros.
+// Forward:  A: u_k = r_k - N_k u_{k-1};  B: u_k = r_k - Nt_k u_{k+1};  root: u_m = r_m - N_m u_{m-1} - Nt_m u_{m+1}.
+// In place in sX (u overwrites r).  NC > 0: compile-time N (fully unrolled), NC == 0: runtime N.
+__device__ __forceinline__ int chain_pos(int k, int m, int N) { return (k <= m) ? k : m + N - k; }
+
+template <int NC>
+__device__ __forceinline__ void chain_forward(const double* sN, double* sX, int Nrt, int lane) {
+  const int N = NC ? NC : Nrt;
+  const int m = N >> 1, LA = m, LB = N - 1 - m;
+  if (LA == 0) return;
+  // opaque to the optimiser: keeps the address arithmetic inside the ADMM loop (hoisted, it gets spilled to scratch)
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const bool rw = (lane & 16) != 0;
+  const bool wr = (lane < 32) && ((lane & 15) < 12);
+  const double* pm = sN + (rw ? m * kSlot : 0) + i;  // step t: + (t-1)*kSlot + c*12
+  double* px = sX + (rw ? (m + 1) * 12 : 0) + i;     // step t: + t*12 (t = 0: the chain's first vector)
+  double x = px[0];
+  double pB = 0.0, mc[12], mn[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) mc[c] = pm[c * 12];
+#pragma unroll
+  for (int t = 1; t <= LA; t++) {
+    const double rk = px[t * 12];  // chain B, t = LB: position N (zeros); t > LB: unused
+    if (t < LA) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) mn[c] = pm[t * kSlot + c * 12];
+    }
+    x = dpp_step12(rk, x, mc);
+    if (t == LB) pB = x;
+    if (wr && (t < LB || (!rw && t < LA))) px[t * 12] = x;
+#pragma unroll
+    for (int c = 0; c < 12; c++) mc[c] = mn[c];
+  }
+  if (LB > 0) x += shfl(pB, lane + 16);
+  if (lane < 12) sX[m * 12 + i] = x;
+}
+// Backward:  x_m = v_m;  A: x_k = v_k - N_{k+1}' x_{k+1} (k = m-1..0);  B: x_k = v_k - Nt_{k-1}' x_{k-1} (k = m+1..N-1).
+// Transposed reads of the same slots (row i of M' is contiguous).
+template <int NC>
+__device__ __forceinline__ void chain_backward(const double* sN, double* sX, int Nrt, int lane) {
+  const int N = NC ? NC : Nrt;
+  const int m = N >> 1, LA = m, LB = N - 1 - m;
+  if (LA == 0) return;
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const bool rw = (lane & 16) != 0;
+  const bool wr = (lane < 32) && ((lane & 15) < 12);
+  const double* pm = sN + (rw ? (N - 1) : m) * kSlot + i * 12;  // step t: - t*kSlot + c
+  double* px = sX + (rw ? N : m) * 12 + i;                       // step t: - t*12
+  double x = sX[m * 12 + i];
+  double mc[12], mn[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) mc[c] = pm[-kSlot + c];
+#pragma unroll
+  for (int t = 1; t <= LA; t++) {
+    const double vk = px[-t * 12];
+    if (t < LA) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) mn[c] = pm[-(t + 1) * kSlot + c];
+    }
+    x = dpp_step12(vk, x, mc);
+    if (wr && (t <= LB || !rw)) px[-t * 12] = x;
+#pragma unroll
+    for (int c = 0; c < 12; c++) mc[c] = mn[c];
+  }
+}
 
 }  // namespace
 
@@ -245,17 +258,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const double mP = has_prev ? 1.0 : 0.0, mP6 = (has_prev && j < 2) ? a.dt : 0.0;
   const double mG = (j >= 2) ? 1.0 : 0.0, mGN = (j >= 2 && has_next) ? 1.0 : 0.0;
   const int kp = has_prev ? k - 1 : k;
-  const int mrow = lane & 15, mq = lane >> 4;  // MFMA operand coordinates
-  // A-operand offsets inside a chain-matrix slot (column-major 12x12): rows 12..15 of the 16-row MFMA tile read
-  // the slot's zero pad, so the loads in the sweeps are unconditional.
-  const int offA_f0 = (mrow < 12) ? (0 + mq) * 12 + mrow : kMatSz;
-  const int offA_f1 = (mrow < 12) ? 4 * 12 : 0;   // relative to offA_f0
-  const int offA_f2 = (mrow < 12) ? 8 * 12 : 0;
-  const int offA_b0 = (mrow < 12) ? mrow * 12 + (0 + mq) : kMatSz;  // transposed read
-  const int offA_b1 = (mrow < 12) ? 4 : 0;
-  const int offA_b2 = (mrow < 12) ? 8 : 0;
-  for (int e = tid; e < (16 * NW - 1) * (kSlot - kMatSz); e += T)
-    L.sN[(e / (kSlot - kMatSz)) * kSlot + kMatSz + e % (kSlot - kMatSz)] = 0.0;
+  const int kx = act ? chain_pos(k, N >> 1, N) : k, kpx = act ? chain_pos(kp, N >> 1, N) : k;  // positions in sX
+  if (tid < 24) L.sX[N * 12 + tid] = 0.0;
+  for (int e = tid; e < kSlot; e += T) L.sN[(16 * NW - 1) * kSlot + e] = 0.0;
 
   // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
   const double dt = a.dt;
@@ -646,34 +651,41 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         }
       }
       wg_sync();
-      // ---- block LDL' recursion over the states (sequential in k, whole wave per step)
+      // ---- twisted block LDL' over the states: chain A (steps 0..m-1 upwards), chain B (steps N-1..m+1 downwards),
+      // then the root step m; sequential in the step, whole workgroup per step
       double* Mprev = L.sA;
       double* Mcur = L.sB;
-      for (int kk = 0; kk < N; kk++) {
+      const int mroot = N >> 1;
+      for (int sidx = 0; sidx < N; sidx++) {
+        // visiting order: 0..m-1, N-1..m+1, m
+        const int kk = (sidx < mroot) ? sidx : (sidx < N - 1) ? (N - 1) - (sidx - mroot) : mroot;
+        const bool isroot = (sidx == N - 1);
+        const bool fromA = isroot ? (mroot > 0) : (kk < mroot && kk > 0);          // couples to an eliminated step kk-1
+        const bool fromB = isroot ? (mroot < N - 1) : (kk > mroot && kk < N - 1);  // couples to an eliminated step kk+1
         const bool last = (kk + 1 == N);
         const double* Wk = &L.sW[kk * kWSz];
         const double* Wn = &L.sW[(last ? kk : kk + 1) * kWSz];
         const double* om = &L.sOm[kk * 12];
         const double* omn = &L.sOm[(last ? kk : kk + 1) * 12];
-        if (kk > 0) {  // N_k = C_k Delta_{k-1}^-1, stored negated, column-major
+        if (fromB) {  // Nt_kk = C_{kk+1}' Delta_{kk+1}^-1 (Mprev), stored negated, column-major, slot m + N-2-kk
 #pragma unroll
           for (int s = 0; s < 3; s++) {
             const int e = tid + T * s;
             if (e < kMatSz) {
               const int i = e / 12, ip = e % 12;
-              double v = -om[i] * Mprev[i * 12 + ip];
-              if (i < 6) v -= dt * om[i] * Mprev[(i + 6) * 12 + ip];
-              else {
+              double v = -omn[i] * Mprev[i * 12 + ip];
+              if (i >= 6) {
+                v -= dt * omn[i - 6] * Mprev[(i - 6) * 12 + ip];
 #pragma unroll
-                for (int m = 0; m < 6; m++) v += Wk[(i - 6) * 6 + m] * Mprev[(6 + m) * 12 + ip];
+                for (int mm = 0; mm < 6; mm++) v += Wn[mm * 6 + (i - 6)] * Mprev[(6 + mm) * 12 + ip];
               }
-              L.sN[(kk - 1) * kSlot + ip * 12 + i] = -v;
+              L.sN[(mroot + N - 2 - kk) * kSlot + ip * 12 + i] = -v;
             }
           }
           wg_sync();
         }
 #pragma unroll
-        for (int s = 0; s < 3; s++) {  // Delta_k = Ttilde_k - N_k C_k'
+        for (int s = 0; s < 3; s++) {  // Delta_kk = Ttilde_kk - N_kk C_kk' - Nt_kk C_{kk+1}
           const int e = tid + T * s;
           if (e < kMatSz) {
             const int i = e / 12, ip = e % 12;
@@ -693,13 +705,23 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
               v -= Wk[(i - 6) * 6 + (ip - 6)];
               if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
             }
-            if (kk > 0) {  // + (-N)[i][m] * C[ip][m]
+            if (fromA) {  // + (-N_kk)[i][m] * C_kk[ip][m]
               const double* nN = &L.sN[(kk - 1) * kSlot];
               double acc = -om[ip] * nN[ip * 12 + i];
               if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * 12 + i];
               else {
 #pragma unroll
-                for (int m = 0; m < 6; m++) acc += Wk[(ip - 6) * 6 + m] * nN[(6 + m) * 12 + i];
+                for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * 12 + i];
+              }
+              v += acc;
+            }
+            if (fromB) {  // + (-Nt_kk)[i][m] * C_{kk+1}[m][ip]
+              const double* nN = &L.sN[(mroot + N - 2 - kk) * kSlot];
+              double acc = -omn[ip] * nN[ip * 12 + i];
+              if (ip >= 6) {
+                acc -= dt * omn[ip - 6] * nN[(ip - 6) * 12 + i];
+#pragma unroll
+                for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * 12 + i];
               }
               v += acc;
             }
@@ -707,7 +729,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           }
         }
         wg_sync();
-        for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_k
+        for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_kk
           double nv[3];
           const double d = 1.0 / Mcur[p * 12 + p];
 #pragma unroll
@@ -734,6 +756,22 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int c = 0; c < 12; c++) Di[t][c] = Mcur[(3 * j + t) * 12 + c];
+        }
+        if (!isroot && kk < mroot) {  // N_{kk+1} = C_{kk+1} Delta_kk^-1, stored negated, column-major, slot kk
+#pragma unroll
+          for (int s = 0; s < 3; s++) {
+            const int e = tid + T * s;
+            if (e < kMatSz) {
+              const int i = e / 12, ip = e % 12;
+              double v = -omn[i] * Mcur[i * 12 + ip];
+              if (i < 6) v -= dt * omn[i] * Mcur[(i + 6) * 12 + ip];
+              else {
+#pragma unroll
+                for (int mm = 0; mm < 6; mm++) v += Wn[(i - 6) * 6 + mm] * Mcur[(6 + mm) * 12 + ip];
+              }
+              L.sN[kk * kSlot + ip * 12 + i] = -v;
+            }
+          }
         }
         double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
         wg_sync();
@@ -791,22 +829,20 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) rX[t] += mGN * gnV[t] - mG * gsV[t];
     }
     PH(2);
-    // ---- 3. block-tridiagonal solve on the matrix cores
+    // ---- 3. block-tridiagonal solve (twisted block LDL', sweeps on the FP64 VALU with DPP row broadcasts)
     if (act) {
 #pragma unroll
-      for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = rX[t];
+      for (int t = 0; t < 3; t++) L.sX[kx * 12 + 3 * j + t] = rX[t];
     }
     wg_sync();
-    // forward sweep u_k = r_k - N_k u_{k-1}, k = 1..N-1 (u_0 = r_0), in place in sX
-    if (wv == 0)
-      chain_sweep((unsigned)(size_t)&L.sN[offA_f0], offA_f1 * 8, offA_f2 * 8, (unsigned)(size_t)&L.sX[12 + mq],
-                (unsigned)(size_t)&L.sX[mq], kSlot * 8, 96, N - 1);
+    // forward sweeps of the twisted factorisation (both chains at once), in place in sX
+    if (wv == 0) chain_forward<FULL ? 16 * NW : 0>(L.sN, L.sX, N, lane);
     wg_sync();
     PH(3);
     {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
       double u[12], v[3];
 #pragma unroll
-      for (int c = 0; c < 12; c++) u[c] = L.sX[k * 12 + c];
+      for (int c = 0; c < 12; c++) u[c] = L.sX[kx * 12 + c];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         double s_ = 0.0;
@@ -817,24 +853,21 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       wg_sync();
       if (act) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = v[t];
+        for (int t = 0; t < 3; t++) L.sX[kx * 12 + 3 * j + t] = v[t];
       }
     }
     wg_sync();
     PH(4);
-    // backward sweep x_k = v_k - N_{k+1}' x_{k+1}, k = N-2..0 (transposed read of the same column-major slots)
-    if (wv == 0)
-      chain_sweep((unsigned)(size_t)&L.sN[(N - 2) * kSlot + offA_b0], offA_b1 * 8, offA_b2 * 8,
-                (unsigned)(size_t)&L.sX[(N - 2) * 12 + mq], (unsigned)(size_t)&L.sX[(N - 1) * 12 + mq], -kSlot * 8, -96,
-                N - 1);
+    // backward sweeps from the root outwards (transposed reads of the same slots)
+    if (wv == 0) chain_backward<FULL ? 16 * NW : 0>(L.sN, L.sX, N, lane);
     wg_sync();
     PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates
     const double cL = (j == 2) ? dtm : 0.0, cA = (j == 3) ? 1.0 : 0.0;
     double dV[6], fh[3], xh[3], xpi[3], xpi6[3];
     {
-      const double* xc = &L.sX[k * 12];
-      const double* xp = &L.sX[kp * 12];
+      const double* xc = &L.sX[kx * 12];
+      const double* xp = &L.sX[kpx * 12];
 #pragma unroll
       for (int c = 0; c < 6; c++) dV[c] = xc[6 + c] - mP * xp[6 + c];
 #pragma unroll
@@ -917,7 +950,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       wg_sync();
       if (act) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) L.sX[k * 12 + 3 * j + t] = xhX[t];
+        for (int t = 0; t < 3; t++) L.sX[kx * 12 + 3 * j + t] = xhX[t];
       }
       wg_sync();
       double pres = 0.0, nz = 0.0, nax = 0.0, pres_s = 0.0, nz_s = 0.0, nax_s = 0.0;
@@ -933,8 +966,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           const int i = 3 * j + t;
           double v = -xhX[t];
           if (has_prev) {
-            v += L.sX[(k - 1) * 12 + i];
-            if (j < 2) v += dt * L.sX[(k - 1) * 12 + i + 6];
+            v += L.sX[kpx * 12 + i];
+            if (j < 2) v += dt * L.sX[kpx * 12 + i + 6];
           }
           if (j == 2) v += dtm * pl[t];
           if (j == 3) v += pa[t];
