@@ -1,0 +1,162 @@
+// Sweeps of the twisted block LDL' (12x12 blocks) on the FP64 VALU with DPP row broadcasts — gfx950 (MI355X).
+// Shared by mpc_kernel.hip and the micro-benchmark scripts/ubench/chain_bench.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "qrw_device.h"
+
+namespace qrw {
+
+constexpr int kCol = 14;           // column stride of a chain matrix in LDS (bank-conflict-free in both orientations)
+constexpr int kSlot = 12 * kCol;  // chain-matrix slot (12x12, column-major)
+
+// ---------------------------------------------------------------------------------------------------------
+// 12x12 row-times-vector step on the FP64 VALU: returns r + sum_c m[c] * x(lane c of this 16-lane row).
+// v_fmac_f64 is a VOP2 on gfx950 and its DPP form takes row_newbcast (the only DPP control FP64 ops accept), so the
+// broadcast of the 12 source entries costs no extra instruction.  One accumulator: a dependent v_fmac_f64 issues
+// every ~5.5 clocks for a lone wavefront, the same as independent ones (scripts/ubench/dpp_rate.hip).
+// One asm statement: the compiler does not model the "VALU write -> DPP read" hazard inside inline asm, hence the
+// leading s_nop 1 (x is usually produced by the instruction just before).
+__device__ __forceinline__ double dpp_step12(double r, double x, const double (&m)[12]) {
+  double a0 = r;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a0)
+      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
+        "v"(m[9]), "v"(m[10]), "v"(m[11]));
+  return a0;
+}
+
+// Twisted (two-ended) block LDL' of the block-tridiagonal state system: chain A eliminates steps 0..m-1 upwards,
+// chain B steps N-1..m+1 downwards, both meet in the root step m = N/2.  Chain A runs in DPP row 0 (lanes 0..11
+// hold vector entries 0..11 and one matrix row each), chain B in row 1, in the same instruction stream; rows 2,3
+// shadow rows 0,1 and store nothing.  Storage is arranged so that both chains walk LDS in the same direction with
+// the same stride (every access is one per-lane base register plus an immediate offset):
+//   matrices (negated, column-major with column stride kCol = 14: entry (i,c) at c*14+i; with that stride both the
+//   forward access -- 12 ds_read_b64, lanes consecutive -- and the transposed one -- 6 ds_read_b128 per lane, 112 B
+//   apart -- are free of bank conflicts, 56 clocks per 12x12 operand, scripts/ubench/lds_rate.hip):
+//     slot s < m : -N_{s+1},        N_k  = C_k Delta_{k-1}^-1        (k = 1..m)
+//     slot s >= m: -Nt_{N-2-(s-m)}, Nt_k = C_{k+1}' Delta_{k+1}^-1   (k = m..N-2; slot m + N-2-k)
+//   vectors: step k lives at position pos(k) = k (k <= m), m + N - k (k > m); position N holds zeros.
+// Forward:  A: u_k = r_k - N_k u_{k-1};  B: u_k = r_k - Nt_k u_{k+1};  root: u_m = r_m - N_m u_{m-1} - Nt_m u_{m+1}.
+// In place in sX (u overwrites r).  NC > 0: compile-time N (fully unrolled), NC == 0: runtime N.
+// Operands are fetched one step ahead into two alternating register buffers (the LDS counter tracks at most 15
+// outstanding operations, a step needs 13 (forward) or 7 (backward)).
+__host__ __device__ __forceinline__ int chain_pos(int k, int m, int N) { return (k <= m) ? k : m + N - k; }
+
+struct ChainOp {
+  double m[12];
+  double r;
+};
+typedef double qrw_d2 __attribute__((ext_vector_type(2)));
+
+// sDump: (NC/2 + 2) * 12 doubles of LDS that absorb the stores of lanes / steps that must not write (cheaper than
+// switching EXEC around every store: a lone wavefront pays full issue time for each scalar instruction).
+template <int NC>
+__device__ __forceinline__ void chain_forward(const double* sN, double* sX, double* sDump, int Nrt, int lane) {
+  const int N = NC ? NC : Nrt;
+  const int m = N >> 1, LA = m, LB = N - 1 - m;
+  if (LA == 0) return;
+  // opaque to the optimiser: keeps the address arithmetic inside the ADMM loop (hoisted, it gets spilled to scratch)
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const bool rw = (lane & 16) != 0;
+  const bool wr = (lane < 32) && ((lane & 15) < 12);
+  const double* pm = sN + (rw ? m * kSlot : 0) + i;  // step t: + (t-1)*kSlot + c*kCol
+  double* px = sX + (rw ? (m + 1) * 12 : 0) + i;     // step t: + t*12 (t = 0: the chain's first vector)
+  double* ps_early = wr ? px : sDump + i;            // stores of steps t < LB
+  double* ps_late = (wr && !rw) ? px : sDump + i;    // stores of steps LB <= t < LA (chain A only)
+  double x = px[0], pB = 0.0;
+  ChainOp b0, b1;
+  auto fetch = [&](ChainOp& b, int t) {
+    const double* q = pm + (t - 1) * kSlot;
+#pragma unroll
+    for (int c = 0; c < 12; c++) {
+#ifndef QRW_CHAIN_READ2
+      // relaxed atomic load: stays a ds_read_b64 (the merged ds_read2_b64 form takes twice as long per byte)
+      b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+      b.m[c] = q[c * kCol];
+#endif
+    }
+    b.r = px[t * 12];  // chain B, t = LB: position N (zeros); t > LB: unused
+  };
+  auto step = [&](const ChainOp& b, int t) {
+    x = dpp_step12(b.r, x, b.m);
+    if (t == LB) pB = x;
+    if (t < LA) (t < LB ? ps_early : ps_late)[t * 12] = x;
+  };
+  fetch(b0, 1);
+#pragma unroll
+  for (int t = 1; t <= LA; t += 2) {  // operands of step t+1 are requested before the 12 FMAs of step t are issued
+    if (t + 1 <= LA) fetch(b1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above the FMAs (the scheduler sinks them otherwise)
+    step(b0, t);
+    if (t + 1 <= LA) {
+      if (t + 2 <= LA) fetch(b0, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      step(b1, t + 1);
+    }
+  }
+  if (LB > 0) x += shfl(pB, lane + 16);
+  if (lane < 12) sX[m * 12 + i] = x;
+}
+// Backward:  x_m = v_m;  A: x_k = v_k - N_{k+1}' x_{k+1} (k = m-1..0);  B: x_k = v_k - Nt_{k-1}' x_{k-1} (k = m+1..N-1).
+// Transposed reads of the same slots (row i of M' is contiguous: 6 ds_read_b128).
+template <int NC>
+__device__ __forceinline__ void chain_backward(const double* sN, double* sX, double* sDump, int Nrt, int lane) {
+  const int N = NC ? NC : Nrt;
+  const int m = N >> 1, LA = m, LB = N - 1 - m;
+  if (LA == 0) return;
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const bool rw = (lane & 16) != 0;
+  const bool wr = (lane < 32) && ((lane & 15) < 12);
+  // both chains walk downwards: step t reads slot (top - t) and vector position (top - t); addressed from the lowest
+  // one so that every immediate offset is non-negative
+  const double* pm = sN + ((rw ? (N - 1) : m) - LA) * kSlot + i * kCol;  // step t: + (LA-t)*kSlot + c
+  double* px = sX + ((rw ? N : m) - LA) * 12 + i;                         // step t: + (LA-t)*12
+  double* ps_early = wr ? px : sDump + i;            // steps t <= LB
+  double* ps_late = (wr && !rw) ? px : sDump + i;    // steps t > LB (chain A only)
+  double x = sX[m * 12 + i];
+  ChainOp b0, b1;
+  auto fetch = [&](ChainOp& b, int t) {
+    const qrw_d2* q = reinterpret_cast<const qrw_d2*>(pm + (LA - t) * kSlot);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const qrw_d2 v = q[c];
+      b.m[2 * c] = v.x;
+      b.m[2 * c + 1] = v.y;
+    }
+    b.r = px[(LA - t) * 12];
+  };
+  auto step = [&](const ChainOp& b, int t) {
+    x = dpp_step12(b.r, x, b.m);
+    (t <= LB ? ps_early : ps_late)[(LA - t) * 12] = x;
+  };
+  fetch(b0, 1);
+#pragma unroll
+  for (int t = 1; t <= LA; t += 2) {
+    if (t + 1 <= LA) fetch(b1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above the FMAs (the scheduler sinks them otherwise)
+    step(b0, t);
+    if (t + 1 <= LA) {
+      if (t + 2 <= LA) fetch(b0, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      step(b1, t + 1);
+    }
+  }
+}
+
+}  // namespace qrw

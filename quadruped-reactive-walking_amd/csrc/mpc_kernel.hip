@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "chain_sweep.h"
 #include "qrw_device.h"
 #include "qrw_kernels.h"
 
@@ -31,7 +32,6 @@ namespace qrw {
 namespace {
 
 constexpr int kMatSz = 144;
-constexpr int kSlot = 144;  // chain-matrix slot (12x12, column-major)
 constexpr int kWSz = 36;
 
 // LDS carve (doubles) for NW wavefronts per instance (16 horizon steps per wavefront): chain matrices -N_k
@@ -41,6 +41,7 @@ struct alignas(16) MpcLdsT {
   static constexpr int S = 16 * NW;
   double sN[S * kSlot];      // S-1 chain matrices (+1 slot only ever read by the idle chain's discarded step)
   double sX[(S + 2) * 12];   // step k at chain_pos(k); position N is a zero vector, N+1 padding for the idle step
+  double sDump[(S / 2 + 2) * 12];  // sink for the sweeps' masked stores
   double sE[S * 12];     // step k <-> k+-1 exchange across wavefronts
   double sW[S * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
   double sOm[S * 12];    // omega_D per step (factor phase)
@@ -131,109 +132,6 @@ __device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int 
     const double r = sRed[0] + sRed[1];
     __syncthreads();
     return r;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 12x12 row-times-vector step on the FP64 VALU: returns r + sum_c m[c] * x(lane c of this 16-lane row).
-// v_fmac_f64 is a VOP2 on gfx950 and its DPP form takes row_newbcast (the only DPP control FP64 ops accept), so the
-// broadcast of the 12 source entries costs no extra instruction.  Two accumulators hide the FMA latency.
-// One asm statement: the compiler does not model the "VALU write -> DPP read" hazard inside inline asm, hence the
-// leading s_nop 1 (x is usually produced by the instruction just before).
-__device__ __forceinline__ double dpp_step12(double r, double x, const double (&m)[12]) {
-  double a0 = r, a1 = 0.0;
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(a0), "+v"(a1)
-      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
-        "v"(m[9]), "v"(m[10]), "v"(m[11]));
-  return a0 + a1;
-}
-
-// Twisted (two-ended) block LDL' of the block-tridiagonal state system: chain A eliminates steps 0..m-1 upwards,
-// chain B steps N-1..m+1 downwards, both meet in the root step m = N/2.  Chain A runs in DPP row 0 (lanes 0..11
-// hold vector entries 0..11 and one matrix row each), chain B in row 1, in the same instruction stream; rows 2,3
-// shadow rows 0,1 and store nothing.  Storage is arranged so that both chains walk LDS in the same direction with
-// the same stride (every access is one per-lane base register plus an immediate offset):
-//   matrices (negated, column-major, entry (i,c) at c*12+i):
-//     slot s < m : -N_{s+1},        N_k  = C_k Delta_{k-1}^-1        (k = 1..m)
-//     slot s >= m: -Nt_{N-2-(s-m)}, Nt_k = C_{k+1}' Delta_{k+1}^-1   (k = m..N-2; slot m + N-2-k)
-//   vectors: step k lives at position pos(k) = k (k <= m), m + N - k (k > m); position N holds zeros.
-// Forward:  A: u_k = r_k - N_k u_{k-1};  B: u_k = r_k - Nt_k u_{k+1};  root: u_m = r_m - N_m u_{m-1} - Nt_m u_{m+1}.
-// In place in sX (u overwrites r).  NC > 0: compile-time N (fully unrolled), NC == 0: runtime N.
-__device__ __forceinline__ int chain_pos(int k, int m, int N) { return (k <= m) ? k : m + N - k; }
-
-template <int NC>
-__device__ __forceinline__ void chain_forward(const double* sN, double* sX, int Nrt, int lane) {
-  const int N = NC ? NC : Nrt;
-  const int m = N >> 1, LA = m, LB = N - 1 - m;
-  if (LA == 0) return;
-  // opaque to the optimiser: keeps the address arithmetic inside the ADMM loop (hoisted, it gets spilled to scratch)
-  asm volatile("" : "+v"(lane));
-  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
-  const bool rw = (lane & 16) != 0;
-  const bool wr = (lane < 32) && ((lane & 15) < 12);
-  const double* pm = sN + (rw ? m * kSlot : 0) + i;  // step t: + (t-1)*kSlot + c*12
-  double* px = sX + (rw ? (m + 1) * 12 : 0) + i;     // step t: + t*12 (t = 0: the chain's first vector)
-  double x = px[0];
-  double pB = 0.0, mc[12], mn[12];
-#pragma unroll
-  for (int c = 0; c < 12; c++) mc[c] = pm[c * 12];
-#pragma unroll
-  for (int t = 1; t <= LA; t++) {
-    const double rk = px[t * 12];  // chain B, t = LB: position N (zeros); t > LB: unused
-    if (t < LA) {
-#pragma unroll
-      for (int c = 0; c < 12; c++) mn[c] = pm[t * kSlot + c * 12];
-    }
-    x = dpp_step12(rk, x, mc);
-    if (t == LB) pB = x;
-    if (wr && (t < LB || (!rw && t < LA))) px[t * 12] = x;
-#pragma unroll
-    for (int c = 0; c < 12; c++) mc[c] = mn[c];
-  }
-  if (LB > 0) x += shfl(pB, lane + 16);
-  if (lane < 12) sX[m * 12 + i] = x;
-}
-// Backward:  x_m = v_m;  A: x_k = v_k - N_{k+1}' x_{k+1} (k = m-1..0);  B: x_k = v_k - Nt_{k-1}' x_{k-1} (k = m+1..N-1).
-// Transposed reads of the same slots (row i of M' is contiguous).
-template <int NC>
-__device__ __forceinline__ void chain_backward(const double* sN, double* sX, int Nrt, int lane) {
-  const int N = NC ? NC : Nrt;
-  const int m = N >> 1, LA = m, LB = N - 1 - m;
-  if (LA == 0) return;
-  asm volatile("" : "+v"(lane));
-  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
-  const bool rw = (lane & 16) != 0;
-  const bool wr = (lane < 32) && ((lane & 15) < 12);
-  const double* pm = sN + (rw ? (N - 1) : m) * kSlot + i * 12;  // step t: - t*kSlot + c
-  double* px = sX + (rw ? N : m) * 12 + i;                       // step t: - t*12
-  double x = sX[m * 12 + i];
-  double mc[12], mn[12];
-#pragma unroll
-  for (int c = 0; c < 12; c++) mc[c] = pm[-kSlot + c];
-#pragma unroll
-  for (int t = 1; t <= LA; t++) {
-    const double vk = px[-t * 12];
-    if (t < LA) {
-#pragma unroll
-      for (int c = 0; c < 12; c++) mn[c] = pm[-(t + 1) * kSlot + c];
-    }
-    x = dpp_step12(vk, x, mc);
-    if (wr && (t <= LB || !rw)) px[-t * 12] = x;
-#pragma unroll
-    for (int c = 0; c < 12; c++) mc[c] = mn[c];
   }
 }
 
@@ -679,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
                 for (int mm = 0; mm < 6; mm++) v += Wn[mm * 6 + (i - 6)] * Mprev[(6 + mm) * 12 + ip];
               }
-              L.sN[(mroot + N - 2 - kk) * kSlot + ip * 12 + i] = -v;
+              L.sN[(mroot + N - 2 - kk) * kSlot + ip * kCol + i] = -v;
             }
           }
           wg_sync();
@@ -707,21 +605,21 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
             }
             if (fromA) {  // + (-N_kk)[i][m] * C_kk[ip][m]
               const double* nN = &L.sN[(kk - 1) * kSlot];
-              double acc = -om[ip] * nN[ip * 12 + i];
-              if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * 12 + i];
+              double acc = -om[ip] * nN[ip * kCol + i];
+              if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * kCol + i];
               else {
 #pragma unroll
-                for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * 12 + i];
+                for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * kCol + i];
               }
               v += acc;
             }
             if (fromB) {  // + (-Nt_kk)[i][m] * C_{kk+1}[m][ip]
               const double* nN = &L.sN[(mroot + N - 2 - kk) * kSlot];
-              double acc = -omn[ip] * nN[ip * 12 + i];
+              double acc = -omn[ip] * nN[ip * kCol + i];
               if (ip >= 6) {
-                acc -= dt * omn[ip - 6] * nN[(ip - 6) * 12 + i];
+                acc -= dt * omn[ip - 6] * nN[(ip - 6) * kCol + i];
 #pragma unroll
-                for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * 12 + i];
+                for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * kCol + i];
               }
               v += acc;
             }
@@ -769,7 +667,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
                 for (int mm = 0; mm < 6; mm++) v += Wn[(i - 6) * 6 + mm] * Mcur[(6 + mm) * 12 + ip];
               }
-              L.sN[kk * kSlot + ip * 12 + i] = -v;
+              L.sN[kk * kSlot + ip * kCol + i] = -v;
             }
           }
         }
@@ -836,7 +734,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     }
     wg_sync();
     // forward sweeps of the twisted factorisation (both chains at once), in place in sX
-    if (wv == 0) chain_forward<FULL ? 16 * NW : 0>(L.sN, L.sX, N, lane);
+    if (wv == 0) chain_forward<FULL ? 16 * NW : 0>(L.sN, L.sX, L.sDump, N, lane);
     wg_sync();
     PH(3);
     {  // v_k = Delta_k^-1 u_k (each quad its own step, in parallel)
@@ -859,7 +757,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     wg_sync();
     PH(4);
     // backward sweeps from the root outwards (transposed reads of the same slots)
-    if (wv == 0) chain_backward<FULL ? 16 * NW : 0>(L.sN, L.sX, N, lane);
+    if (wv == 0) chain_backward<FULL ? 16 * NW : 0>(L.sN, L.sX, L.sDump, N, lane);
     wg_sync();
     PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates

@@ -8,6 +8,28 @@
 #define FM(J) "v_fmac_f64_dpp %0, %2, %" #J "+3 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
 #define FM1(J) "v_fmac_f64_dpp %1, %2, %" #J "+3 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
 
+#if ACC == 1
+__device__ __forceinline__ double step12(double r, double x, const double m[12]) {
+  double a0 = r;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a0)
+      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
+        "v"(m[9]), "v"(m[10]), "v"(m[11]));
+  return a0;
+}
+#else
 __device__ __forceinline__ double step12(double r, double x, const double m[12]) {
   double a0 = r, a1 = 0.0;
   asm("s_nop 1\n\t"
@@ -28,8 +50,17 @@ __device__ __forceinline__ double step12(double r, double x, const double m[12])
         "v"(m[9]), "v"(m[10]), "v"(m[11]));
   return a0 + a1;
 }
+#endif
 
-constexpr int kSteps = 15, kSlot = 144;
+#ifndef CS
+#define CS 12
+#endif
+#ifndef TR
+#define TR 0
+#endif
+constexpr int kSteps = 15, kSlot = 12 * CS;
+// entry (i,c) of a step's matrix: TR=0 at i*CS+c (lane reads contiguous), TR=1 at c*CS+i (lane reads strided)
+#define MIDX(i, c) (TR ? (c) * CS + (i) : (i) * CS + (c))
 
 __global__ void k_chain(const double* M, const double* r, double* out, unsigned long long* cyc) {
   __shared__ double sM[4][kSteps * kSlot];
@@ -41,22 +72,33 @@ __global__ void k_chain(const double* M, const double* r, double* out, unsigned 
   __syncthreads();
   const int ii = i < 12 ? i : 11;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (lane < ACTIVE) {
   double x = sR[row][ii];
   sU[row][ii] = x;
-  double m[12], mn[12];
+  double m[12], mn[12], rk = sR[row][12 + ii], rn = 0.0;
 #pragma unroll
-  for (int c = 0; c < 12; c++) m[c] = sM[row][ii * 12 + c];
+  for (int c = 0; c < 12; c++) m[c] = sM[row][MIDX(ii, c)];
 #pragma unroll
   for (int k = 1; k <= kSteps; k++) {
-    const double rk = sR[row][k * 12 + ii];
+#ifndef NOLOAD
     if (k < kSteps) {
+      rn = sR[row][(k + 1) * 12 + ii];
 #pragma unroll
-      for (int c = 0; c < 12; c++) mn[c] = sM[row][k * kSlot + ii * 12 + c];
+      for (int c = 0; c < 12; c++) mn[c] = sM[row][k * kSlot + MIDX(ii, c)];
     }
+#else
+    rn = rk * 0.5;
+#pragma unroll
+    for (int c = 0; c < 12; c++) mn[c] = m[c];
+#endif
     x = step12(rk, x, m);
+#ifndef NOSTORE
     sU[row][k * 12 + ii] = x;
+#endif
+    rk = rn;
 #pragma unroll
     for (int c = 0; c < 12; c++) m[c] = mn[c];
+  }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   __syncthreads();
@@ -75,7 +117,7 @@ int main() {
     for (int k = 1; k <= kSteps; k++)
       for (int i = 0; i < 12; i++) {
         double s = rr[k * 12 + i];
-        for (int c = 0; c < 12; c++) s += M[p * kSteps * kSlot + (k - 1) * kSlot + i * 12 + c] * u[(k - 1) * 12 + c];
+        for (int c = 0; c < 12; c++) s += M[p * kSteps * kSlot + (k - 1) * kSlot + MIDX(i, c)] * u[(k - 1) * 12 + c];
         u[k * 12 + i] = s;
       }
   }
@@ -92,7 +134,7 @@ int main() {
   hipMemcpy(out.data(), dout, r.size() * 8, hipMemcpyDeviceToHost);
   double err = 0, mx = 0;
   for (size_t e = 0; e < r.size(); e++) { err = fmax(err, fabs(out[e] - ref[e])); mx = fmax(mx, fabs(ref[e])); }
-  printf("dpp chain: %d steps, %llu memtime ticks total, %.1f per step; max err %.3e (max |u| %.3e)\n", kSteps, c,
+  printf("CS=%d TR=%d ACC=%d ACTIVE=%d dpp chain: %d steps, %llu memtime ticks total, %.1f per step; max err %.3e (max |u| %.3e)\n", CS, TR, ACC, ACTIVE, kSteps, c,
          (double)c / kSteps, err, mx);
   return err <= 1e-12 * mx ? 0 : 1;
 }
