@@ -65,12 +65,12 @@ def test_mixed_gaits_match_oracle(oracle_mod, synth_mod):
     run_sequence(oracle_mod, synth_mod, 10, 16, ("walk", "trot", "bounding", "pacing", "static"), 6, 31000)
 
 
-@pytest.mark.parametrize("N", [4, 8, 12])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 8, 12, 15])
 def test_short_horizons(oracle_mod, synth_mod, N):
     run_sequence(oracle_mod, synth_mod, 3, N, ("trot",), 4, 41000 + N)
 
 
-@pytest.mark.parametrize("N", [17, 24, 32])
+@pytest.mark.parametrize("N", [17, 24, 31, 32])
 def test_long_horizons_two_wavefronts(oracle_mod, synth_mod, N):
     """N > 16 runs two wavefronts per instance (BASELINE config 4: N = 32, mixed walk/trot/bound schedules)."""
     eng, refs, worst = run_sequence(oracle_mod, synth_mod, 5, N, ("walk", "trot", "bounding"), 5, 43000 + N)
