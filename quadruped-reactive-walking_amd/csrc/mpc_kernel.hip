@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   constexpr int T = 64 * NW;  // threads per instance
   // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
   // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
+  PH_DECL
   const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
@@ -435,13 +436,13 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 
   // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
-  PH_DECL
   bool need_factor = true;
   int iter = 0, status = kStatusUnsolved, rho_updates = 0;
   double pri_res = 0.0, dua_res = 0.0, last_np = 0.0, last_nd = 0.0;
   const int max_iter = 4000;
   rho = fmin(fmax(rho, kRhoMin), kRhoMax);
 
+  PH(8);
   for (iter = 1; iter <= max_iter; iter++) {
     PH(9);
     if (need_factor) {

@@ -39,11 +39,18 @@ __device__ __forceinline__ double quad_max(double v) {
   return v;
 }
 __device__ __forceinline__ double shfl(double v, int src) { return __shfl(v, src, 64); }
+// max over the wavefront, result uniform: quad (DPP quad_perm), 16-lane row (DPP row_ror 4, 8), then the four rows
+// through v_readlane -- no LDS round trips (the ds_bpermute butterfly costs four dependent ~100-clock trips)
 __device__ __forceinline__ double wave_max(double v) {
   v = quad_max(v);
-#pragma unroll
-  for (int m = 4; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
-  return v;
+  v = fmax(v, dpp_quad<0x124>(v));  // row_ror:4
+  v = fmax(v, dpp_quad<0x128>(v));  // row_ror:8
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return fmax(fmax(r0, r1), fmax(r2, r3));
 }
 __device__ __forceinline__ double wave_sum(double v) {
   v = quad_sum(v);

@@ -1,0 +1,33 @@
+"""How good is the longest-first block order? Collects per-instance ADMM iteration counts over consecutive solves of
+the bench workload and simulates list scheduling on 1024 SIMD slots with (a) the previous solve's counts as the
+order (what the order kernel does), (b) the actual counts (oracle order), against the lower bound."""
+import heapq, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
+import numpy as np
+import qrw_hip, synth
+
+def makespan(order, w, slots=1024):
+    h = [0.0] * slots
+    heapq.heapify(h)
+    for i in order:
+        t = heapq.heappop(h)
+        heapq.heappush(h, t + w[i])
+    return max(h)
+
+B, N = 4096, 16
+sb = synth.SyntheticBatch(B, N)
+g = qrw_hip.Batch(B, N)
+prev = None
+for s in range(10):
+    d = sb.step(s)
+    g.mpc_solve_host(d["xref"], d["fsteps"], s)
+    it = g.mpc_stats()["iters"].astype(float) + 9.0  # + setup/factor overhead in iteration units
+    if prev is not None and s >= 3:
+        lb = max(it.max(), it.sum() / 1024)
+        a = makespan(np.argsort(-prev, kind="stable"), it)
+        b = makespan(np.argsort(-it, kind="stable"), it)
+        c = makespan(np.arange(B), it)
+        print("step %d: mean %.0f max %.0f | lower bound %.0f | order by previous counts %.0f (%.2fx) | by actual counts %.0f (%.2fx) | index order %.0f (%.2fx) | corr(prev,cur) %.3f"
+              % (s, it.mean(), it.max(), lb, a, a / lb, b, b / lb, c, c / lb, np.corrcoef(prev, it)[0, 1]))
+    prev = it

@@ -5,7 +5,7 @@ os.environ["QRW_HIP_LIB"] = os.path.join(ROOT, "build", "libqrw_hip_prof.so")
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, time
 import qrw_hip, synth
-names = ["factor", "rhs", "elim_g", "fwd_chain", "middle", "bwd_chain", "backsub+A+upd", "tail", "-", "check+loop"]
+names = ["factor", "rhs", "elim_g", "fwd_chain", "middle", "bwd_chain", "backsub+A+upd", "tail", "setup (assemble+Ruiz)", "check+rho"]
 for B in (8, 4096):
     sb = synth.SyntheticBatch(B, 16)
     g = qrw_hip.Batch(B, 16)
