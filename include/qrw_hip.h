@@ -200,8 +200,20 @@ int qrw_controller_result(qrw_handle h, const double *d_tau_ff, const double *d_
                           const double *d_q_filt, const double *d_v_secu, double *d_result, int32_t *d_error_flag,
                           void *stream);
 
-/* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 has the operand layout the MPC
- * chain sweeps assume. 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
+/* ---------------- asynchronous MPC ----------------
+ * The reference runs the MPC in a child process on its own CPU core and polls a shared flag
+ * (scripts/MPC_Wrapper.py:150-298).  Here the MPC gets its own HIP stream restricted to a subset of the compute
+ * units, so that the control loop's kernels (planners, WBC, glue) on a second stream restricted to the remaining
+ * units never queue behind a running solve.  Creates a stream whose kernels only run on compute units
+ * [first_cu, first_cu + n_cus) of `device` (hipExtStreamCreateWithCUMask); n_cus <= 0 = no restriction. */
+int qrw_stream_create(int32_t device, int32_t first_cu, int32_t n_cus, void **stream);
+int qrw_stream_destroy(void *stream);
+/* number of compute units of the device (256 on MI355X) */
+int qrw_device_cu_count(int32_t device, int32_t *n_cus);
+
+/* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 accumulates a 12x12 matrix-vector product in the
+ * operand layout the first version of the MPC sweeps used (the sweeps now run on the FP64 VALU with DPP row
+ * broadcasts, csrc/chain_sweep.h). 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
 int qrw_selftest_mfma(double *max_err);
 
 /* workspace sizes, for callers that budget HBM */

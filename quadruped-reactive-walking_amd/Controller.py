@@ -21,8 +21,17 @@ class Result:
 
 class Controller_batch:
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
-                 h_ref=0.2229, device=0):
-        """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60)."""
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None):
+        """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
+
+        multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
+        on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
+        compute units but `loop_cus`, the control loop (planners, glue, WBC) on a stream restricted to those
+        `loop_cus` units, so an iteration never queues behind a running solve.  A finished solve is adopted by the
+        first iteration that finds its event complete (mpc_lag=None, what the reference's flag polling does), or --
+        deterministic, for tests and replay -- exactly `mpc_lag` iterations after it was issued.
+        The masked streams are ordinary (blocking) HIP streams: they synchronise with the legacy default stream, so call
+        compute() from a non-default stream (`with torch.cuda.stream(torch.cuda.Stream()): ...`) or the overlap is lost."""
         import torch
 
         self._torch = torch
@@ -44,17 +53,84 @@ class Controller_batch:
         self._not_first_iter = False
         self._st = self._plan = self._wi = self._wbc = self._res = None
         self.x_f_mpc = self._mpc_default
+        self.multiprocessing = bool(multiprocessing)
+        self.mpc_lag = mpc_lag
+        if self.multiprocessing:
+            n_cu = qrw_hip.device_cu_count(device)
+            loop_cus = max(1, min(int(loop_cus), n_cu - 1))
+            self._s_loop = qrw_hip.CuStream(device, 0, loop_cus)
+            self._s_mpc = qrw_hip.CuStream(device, loop_cus, n_cu - loop_cus)
+            Ng = int(N_gait)
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.dev)
+            self._snap = [(mk(self.B, 12, self.n_steps + 1), mk(self.B, Ng, 12)) for _ in range(3)]
+            self._outs = [mk(self.B, 24, self.n_steps) for _ in range(3)]
+            self._ev_in = [torch.cuda.Event() for _ in range(3)]
+            self._ev_done = [torch.cuda.Event() for _ in range(3)]
+            self._n_issued = 0          # number of solves issued so far
+            self._pending = []          # [(solve index, iteration it was issued at)] not adopted yet
+            self._adopted = None        # index (mod 3) of the buffer the loop currently reads
 
     def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
         """One control iteration for every instance. All arguments CUDA float64 with leading dimension B:
         joy_v_ref (B,6), q_filt (B,19), v_filt (B,18), rpy (B,3), v_secu (B,12). Returns the Result views."""
+        if not self.multiprocessing:
+            return self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+        torch = self._torch
+        caller = torch.cuda.current_stream(self.dev)
+        self._s_loop.torch.wait_stream(caller)
+        with torch.cuda.stream(self._s_loop.torch):
+            r = self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+        caller.wait_stream(self._s_loop.torch)
+        return r
+
+    def _solve_async(self, plan, k):
+        """scripts/MPC_Wrapper.py:150-180 (run_MPC_asynchronous): hand the planner outputs to the MPC and return."""
+        torch = self._torch
+        n = self._n_issued
+        i = n % 3
+        if self._adopted == i and self._pending:  # the loop still reads the buffer this solve will write: catch up
+            self._adopt(self._pending[-1][0], wait=True)
+        xs, fs = self._snap[i]
+        xs.copy_(plan["xref"])
+        fs.copy_(plan["fsteps"])
+        self._ev_in[i].record(self._s_loop.torch)
+        self._s_mpc.torch.wait_event(self._ev_in[i])
+        with torch.cuda.stream(self._s_mpc.torch):
+            self._b.mpc_solve(xs, fs, k, out=self._outs[i])
+            self._ev_done[i].record(self._s_mpc.torch)
+        self._pending.append((n, k))
+        self._n_issued = n + 1
+
+    def _adopt(self, n, wait):
+        i = n % 3
+        if wait:
+            self._s_loop.torch.wait_event(self._ev_done[i])
+        self._mpc_out = self._outs[i]
+        self._adopted = i
+        self._pending = [p for p in self._pending if p[0] > n]
+
+    def _poll(self, k):
+        """scripts/MPC_Wrapper.py:106-120: take the newest finished result, if any."""
+        ready = None
+        for n, k0 in self._pending:
+            if (self.mpc_lag is None and self._ev_done[n % 3].query()) or (self.mpc_lag is not None and k >= k0 + self.mpc_lag):
+                ready = n
+        if ready is not None:
+            self._adopt(ready, wait=self.mpc_lag is not None)
+
+    def _compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code):
         b, k = self._b, self.k
         self._st = st = b.controller_update_state(joy_v_ref, q_filt, v_filt, rpy, out=self._st)
         self._plan = plan = b.planner_step(k, st["q"][:, :7].contiguous(), st["h_v"], st["v_ref"], joystick_code,
                                            out=self._plan)
         if (k % self.k_mpc) == 0:
-            self._mpc_out = b.mpc_solve(plan["xref"], plan["fsteps"], k, out=self._mpc_out)
-        if self._not_first_iter:
+            if self.multiprocessing:
+                self._solve_async(plan, k)
+            else:
+                self._mpc_out = b.mpc_solve(plan["xref"], plan["fsteps"], k, out=self._mpc_out)
+        if self.multiprocessing:
+            self._poll(k)
+        if self._not_first_iter and self._mpc_out is not None:
             self.x_f_mpc = self._mpc_out
         else:
             self._not_first_iter = True
@@ -68,6 +144,15 @@ class Controller_batch:
         self.error_flag = self._res["error_flag"]
         self.k += 1
         return self.result
+
+    def stop_parallel_loop(self):
+        """scripts/MPC_Wrapper.py:300-306: drain the MPC stream and release both streams."""
+        if self.multiprocessing:
+            self._s_mpc.torch.synchronize()
+            self._s_loop.torch.synchronize()
+            self._s_mpc.close()
+            self._s_loop.close()
+            self.multiprocessing = False
 
     def stats(self):
         return dict(mpc=self._b.mpc_stats(), wbc=self._b.wbc_stats())

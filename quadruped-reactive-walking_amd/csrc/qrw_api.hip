@@ -566,3 +566,39 @@ extern "C" int qrw_controller_result(qrw_handle h, const double* d_tau_ff, const
   a.out0 = d_result; a.iout = d_error_flag;
   return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_controller_result: launch failed", hipGetLastError()) : 0;
 }
+
+// ------------------------------------------------------------------ streams on a subset of the compute units
+extern "C" int qrw_device_cu_count(int32_t device, int32_t* n_cus) {
+  if (!n_cus) return fail(-1, "qrw_device_cu_count: null argument");
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(-10, "qrw_device_cu_count: hipGetDeviceProperties failed", e);
+  *n_cus = prop.multiProcessorCount;
+  return 0;
+}
+extern "C" int qrw_stream_create(int32_t device, int32_t first_cu, int32_t n_cus, void** stream) {
+  if (!stream) return fail(-1, "qrw_stream_create: null argument");
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(-10, "qrw_stream_create: hipSetDevice failed", e);
+  hipStream_t s = nullptr;
+  if (n_cus <= 0) {
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  } else {
+    int32_t total = 0;
+    if (qrw_device_cu_count(device, &total)) return -10;
+    if (first_cu < 0 || first_cu + n_cus > total) return fail(-1, "qrw_stream_create: compute-unit range outside the device");
+    const int words = (total + 31) / 32;
+    uint32_t mask[64] = {0};
+    if (words > 64) return fail(-1, "qrw_stream_create: device has more than 2048 compute units");
+    for (int c = first_cu; c < first_cu + n_cus; c++) mask[c >> 5] |= 1u << (c & 31);
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  }
+  if (e != hipSuccess) return fail(-10, "qrw_stream_create: stream creation failed", e);
+  *stream = (void*)s;
+  return 0;
+}
+extern "C" int qrw_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? 0 : fail(-10, "qrw_stream_destroy: hipStreamDestroy failed", e);
+}

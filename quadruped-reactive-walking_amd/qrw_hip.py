@@ -64,6 +64,9 @@ SIGNATURES = {
     "qrw_controller_update_state": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_wbc_inputs": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_result": (C.c_int, [_vp] + [_vp] * 7 + [_vp]),
+    "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "qrw_stream_destroy": (C.c_int, [_vp]),
+    "qrw_device_cu_count": (C.c_int, [C.c_int32, _ip]),
     "qrw_selftest_mfma": (C.c_int, [_dp]),
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
@@ -107,6 +110,38 @@ def _h(a, shape):
 
 def _p(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def device_cu_count(device=0):
+    n = C.c_int32(0)
+    _check(load_library().qrw_device_cu_count(int(device), C.byref(n)), "qrw_device_cu_count")
+    return n.value
+
+
+class CuStream:
+    """A HIP stream restricted to compute units [first_cu, first_cu + n_cus) (all units if n_cus <= 0), wrapped as a
+    torch.cuda.ExternalStream in `.torch` so that torch tensors / events and `with torch.cuda.stream(...)` work on it."""
+
+    def __init__(self, device=0, first_cu=0, n_cus=0):
+        import torch
+
+        self._lib = load_library()
+        p = _vp()
+        _check(self._lib.qrw_stream_create(int(device), int(first_cu), int(n_cus), C.byref(p)), "qrw_stream_create")
+        self.ptr = p.value
+        self.torch = torch.cuda.ExternalStream(self.ptr, device=torch.device("cuda:%d" % device))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.torch.synchronize()
+            self._lib.qrw_stream_destroy(_vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def selftest_mfma():

@@ -76,16 +76,20 @@ def test_glue_stages_match_oracle():
     assert [r.error_flag for r in refs] == [0, 1, 3, 3, 2, 0, 0]
 
 
-def test_closed_loop_matches_chained_oracles(oracle_mod):
+@pytest.mark.parametrize("mode", ["sync", "async_lag0", "async_lag3"])
+def test_closed_loop_matches_chained_oracles(oracle_mod, mode):
     """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
-    made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state."""
+    made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state.  The
+    asynchronous modes run the MPC on its own compute-unit-masked stream and adopt a result a fixed number of
+    iterations after it was issued (lag 0 = the synchronous semantics)."""
     import torch
     import controller_oracle as co
     from Controller import Controller_batch
 
     B, iters = 5, 45
+    lag = {"sync": 0, "async_lag0": 0, "async_lag3": 3}[mode]
     rng = np.random.default_rng(3)
-    ctl = Controller_batch(B, Q_INIT)
+    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag)
     glue = [co.ControllerGlue(Q_INIT, 0.2229, 0.002) for _ in range(B)]
     plan = [oracle_mod.Planner() for _ in range(B)]
     mpc = [oracle_mod.MPC(0.02, 16, 0.32, 20) for _ in range(B)]
@@ -94,6 +98,8 @@ def test_closed_loop_matches_chained_oracles(oracle_mod):
     first[2, 0] = 0.2229
     first[12:, 0] = [0.0, 0.0, 8.0] * 4
     not_first = [False] * B
+    issued = [[] for _ in range(B)]     # (iteration issued, result) per instance
+    adopted = [None] * B
     vref = rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0])
     qf = np.zeros((B, 19))
     qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
@@ -115,7 +121,11 @@ def test_closed_loop_matches_chained_oracles(oracle_mod):
             xref, (fsteps, _, _), cgait = plan[b].xref(), plan[b].footsteps(), plan[b].gaits()[1]
             if k % 10 == 0:
                 mpc[b].run(k, xref, fsteps)
-            x_f_mpc = mpc[b].get_latest_result() if not_first[b] else first
+                issued[b].append((k, mpc[b].get_latest_result().copy()))
+            for k0, res_ in issued[b]:
+                if k >= k0 + lag:
+                    adopted[b] = res_
+            x_f_mpc = adopted[b] if (not_first[b] and adopted[b] is not None) else first
             not_first[b] = True
             pos, vel, acc, _, _ = plan[b].feet()
             xw, qw, bv = g.wbc_inputs(x_f_mpc, xref, oRh, oTh, pos, vel, acc)
@@ -130,4 +140,29 @@ def test_closed_loop_matches_chained_oracles(oracle_mod):
         qf, vf = nq, nv
     st = ctl.stats()
     assert np.all(st["mpc"]["status"] == 1)
-    print("closed loop worst relative deviation %.2e" % worst)
+    ctl.stop_parallel_loop()
+    print("closed loop (%s) worst relative deviation %.2e" % (mode, worst))
+
+
+def test_async_polling_mode_runs():
+    """The production asynchronous mode adopts a result when its event has completed (timing dependent, like the
+    reference's shared-flag polling): check it runs, stays in the nominal regime and ends up using MPC results."""
+    import torch
+    from Controller import Controller_batch
+
+    B = 64
+    ctl = Controller_batch(B, Q_INIT, multiprocessing=True)
+    vref = _t(np.tile(np.array([0.3, 0.0, 0, 0, 0, 0.1]), (B, 1)))
+    qf = np.zeros((B, 19))
+    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+    qf, vf = _t(qf), _t(np.zeros((B, 18)))
+    rpy, vs = _t(np.zeros((B, 3))), _t(np.zeros((B, 12)))
+    for k in range(60):
+        r = ctl.compute(vref, qf, vf, rpy, vs)
+        qf[:, 7:].copy_(r.q_des)
+        vf[:, 6:].copy_(r.v_des)
+    torch.cuda.synchronize()
+    assert ctl._adopted is not None and ctl._n_issued == 6
+    assert int((ctl.error_flag != 0).sum().item()) == 0
+    assert bool(torch.isfinite(ctl._res["result"]).all())
+    ctl.stop_parallel_loop()
