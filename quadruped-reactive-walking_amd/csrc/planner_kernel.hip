@@ -9,8 +9,9 @@
 // HBM in the layouts the solver kernels read, so a control step needs no host round trip.
 //
 // Mapping: one thread per robot instance (the planners are a few thousand scalar operations with data-dependent
-// control flow; they cost ~1 % of the MPC solve).  Persistent planner state is item-major, ps[item][instance],
-// so the threads of a wavefront read and write consecutive addresses.
+// control flow).  Persistent planner state is item-major, ps[item][instance], so the threads of a wavefront read
+// and write consecutive addresses; inside the kernel the gait matrices are bit masks and the foot trajectories
+// statically indexed register arrays (see below), the state is only touched at the kernel's edges.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -59,94 +60,137 @@ __host__ __device__ inline Lay make_layout(int Ng) {
   return L;
 }
 
-__device__ __forceinline__ bool row_zero(const PS& s, int m, int i) {
-  return s(m + i * 4) == 0.0 && s(m + i * 4 + 1) == 0.0 && s(m + i * 4 + 2) == 0.0 && s(m + i * 4 + 3) == 0.0;
+// ---------------------------------------------------------------------------------------------------------
+// The reference keeps the three gait matrices (past / current / desired, N_gait x 4 entries that are only ever
+// 0 or 1) as dense double matrices and rolls them with chains of row swaps; run literally against HBM that is
+// thousands of dependent memory round trips per control iteration.  Here a matrix is four 64-bit column masks in
+// registers (bit i = row i), unpacked from / packed back into the double-valued state at the kernel's edges, so
+// "row i is all zero", "roll rows 0..n" and the phase-duration scans are a few integer instructions.  The
+// footstep table is produced row by row from registers and written once; the foot trajectory state is held in
+// statically indexed register arrays (the swing-feet list becomes a 4-bit mask).
+struct Gm {
+  unsigned long long c[4];
+};
+__device__ __forceinline__ unsigned long long gm_any(const Gm& m) { return m.c[0] | m.c[1] | m.c[2] | m.c[3]; }
+__device__ __forceinline__ bool rz(const Gm& m, int i) { return ((gm_any(m) >> i) & 1ull) == 0ull; }
+__device__ __forceinline__ bool gbit(const Gm& m, int i, int j) {
+  const unsigned long long col = (j == 0) ? m.c[0] : (j == 1) ? m.c[1] : (j == 2) ? m.c[2] : m.c[3];
+  return ((col >> i) & 1ull) != 0ull;
 }
-__device__ __forceinline__ void row_swap(const PS& s, int m, int a, int b) {
+__device__ __forceinline__ unsigned long long lowmask(int n) { return (n >= 64) ? ~0ull : ((1ull << n) - 1ull); }
+// rows 0..n-1: new[r] = old[r+1] (r < n-1), new[n-1] = old[0]   (what "swap(0,1), swap(1,2), ..., swap(n-2,n-1)" does)
+__device__ __forceinline__ void rot_up(Gm& m, int n) {
+  if (n < 2) return;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const double t = s(m + a * 4 + j);
-    s(m + a * 4 + j) = s(m + b * 4 + j);
-    s(m + b * 4 + j) = t;
+  for (int c = 0; c < 4; c++) {
+    const unsigned long long lo = m.c[c] & lowmask(n), hi = m.c[c] & ~lowmask(n);
+    m.c[c] = hi | (lo >> 1) | ((lo & 1ull) << (n - 1));
   }
 }
-__device__ __forceinline__ void rows_fill(const PS& s, int m, int r0, int n, double a, double b, double c, double d) {
-  for (int r = r0; r < r0 + n; r++) { s(m + r * 4) = a; s(m + r * 4 + 1) = b; s(m + r * 4 + 2) = c; s(m + r * 4 + 3) = d; }
+// rows 0..n-1: new[0] = old[n-1], new[r] = old[r-1]              ("swap(n-1,n-2), ..., swap(1,0)")
+__device__ __forceinline__ void rot_down(Gm& m, int n) {
+  if (n < 2) return;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const unsigned long long lo = m.c[c] & lowmask(n), hi = m.c[c] & ~lowmask(n);
+    m.c[c] = hi | ((lo << 1) & lowmask(n)) | ((lo >> (n - 1)) & 1ull);
+  }
+}
+__device__ __forceinline__ void rows_fill(Gm& m, int r0, int n, bool a, bool b, bool c, bool d) {
+  const unsigned long long f = lowmask(n) << r0;
+  if (a) m.c[0] |= f;
+  if (b) m.c[1] |= f;
+  if (c) m.c[2] |= f;
+  if (d) m.c[3] |= f;
+}
+__device__ void gm_load(const PS& s, int item, int Ng, Gm& m) {
+  m.c[0] = m.c[1] = m.c[2] = m.c[3] = 0ull;
+#pragma unroll 4
+  for (int i = 0; i < Ng; i++) {
+    const double v0 = s(item + i * 4), v1 = s(item + i * 4 + 1), v2 = s(item + i * 4 + 2), v3 = s(item + i * 4 + 3);
+    m.c[0] |= (unsigned long long)(v0 != 0.0) << i;
+    m.c[1] |= (unsigned long long)(v1 != 0.0) << i;
+    m.c[2] |= (unsigned long long)(v2 != 0.0) << i;
+    m.c[3] |= (unsigned long long)(v3 != 0.0) << i;
+  }
+}
+__device__ void gm_store(const PS& s, int item, int Ng, const Gm& m) {
+#pragma unroll 4
+  for (int i = 0; i < Ng; i++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) s(item + i * 4 + c) = ((m.c[c] >> i) & 1ull) ? 1.0 : 0.0;
 }
 
 // desired gait of one period (src/Gait.cpp:38-108); code 5 = walk (exists in the reference but is not reachable there)
-__device__ void create_desired(const PS& s, const Lay& L, const PlannerArgs& a, int code) {
-  for (int e = 0; e < a.N_gait * 4; e++) s(L.des + e) = 0.0;
+__device__ void create_desired(Gm& des, const PlannerArgs& a, int code) {
+  des.c[0] = des.c[1] = des.c[2] = des.c[3] = 0ull;
   const int Nh = (int)lround(0.5 * a.T_gait / a.dt_mpc);
-  if (code == 1) { rows_fill(s, L.des, 0, Nh, 1, 0, 1, 0); rows_fill(s, L.des, Nh, Nh, 0, 1, 0, 1); }
-  else if (code == 2) { rows_fill(s, L.des, 0, Nh, 1, 1, 0, 0); rows_fill(s, L.des, Nh, Nh, 0, 0, 1, 1); }
-  else if (code == 3) { rows_fill(s, L.des, 0, Nh, 1, 0, 0, 1); rows_fill(s, L.des, Nh, Nh, 0, 1, 1, 0); }
-  else if (code == 4) { rows_fill(s, L.des, 0, (int)lround(a.T_gait / a.dt_mpc), 1, 1, 1, 1); }
+  if (code == 1) { rows_fill(des, 0, Nh, 1, 0, 1, 0); rows_fill(des, Nh, Nh, 0, 1, 0, 1); }
+  else if (code == 2) { rows_fill(des, 0, Nh, 1, 1, 0, 0); rows_fill(des, Nh, Nh, 0, 0, 1, 1); }
+  else if (code == 3) { rows_fill(des, 0, Nh, 1, 0, 0, 1); rows_fill(des, Nh, Nh, 0, 1, 1, 0); }
+  else if (code == 4) { rows_fill(des, 0, (int)lround(a.T_gait / a.dt_mpc), 1, 1, 1, 1); }
   else if (code == 5) {
     const int Nq = (int)lround(0.25 * a.T_gait / a.dt_mpc);
-    rows_fill(s, L.des, 0, Nq, 0, 1, 1, 1); rows_fill(s, L.des, Nq, Nq, 1, 0, 1, 1);
-    rows_fill(s, L.des, 2 * Nq, Nq, 1, 1, 0, 1); rows_fill(s, L.des, 3 * Nq, Nq, 1, 1, 1, 0);
+    rows_fill(des, 0, Nq, 0, 1, 1, 1); rows_fill(des, Nq, Nq, 1, 0, 1, 1);
+    rows_fill(des, 2 * Nq, Nq, 1, 1, 0, 1); rows_fill(des, 3 * Nq, Nq, 1, 1, 1, 0);
   }
 }
 
 // Gait::initialize (src/Gait.cpp:19-36) + create_gait_f (:110-139)
-__device__ void gait_init(const PS& s, const Lay& L, const PlannerArgs& a) {
-  for (int e = 0; e < a.N_gait * 4; e++) { s(L.past + e) = 0.0; s(L.cur + e) = 0.0; }
-  create_desired(s, L, a, 3);
+__device__ void gait_init(Gm& past, Gm& cur, Gm& des, const PlannerArgs& a) {
+  past.c[0] = past.c[1] = past.c[2] = past.c[3] = 0ull;
+  cur = past;
+  create_desired(des, a, 3);
   int i = 0;
   for (int j = 0; j < a.n_steps; j++) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) s(L.cur + j * 4 + c) = s(L.des + i * 4 + c);
+    for (int c = 0; c < 4; c++) cur.c[c] |= ((des.c[c] >> i) & 1ull) << j;
     i++;
-    if (row_zero(s, L.des, i)) i = 0;
+    if (rz(des, i)) i = 0;
   }
   int index = 1;
-  while (!row_zero(s, L.des, index)) index++;
-  for (int k = 0; k < i; k++)
-    for (int m = 0; m < index - 1; m++) row_swap(s, L.des, m, m + 1);
-  s(L.newphase) = 0.0; s(L.isstatic) = 0.0; s(L.remain) = 0.0; s(L.nfeet) = 0.0;
+  while (!rz(des, index)) index++;
+  for (int k = 0; k < i; k++) rot_up(des, index);
 }
 
 // Gait::getPhaseDuration (src/Gait.cpp:141-182); also leaves remainingTime_
-__device__ double phase_duration(const PS& s, const Lay& L, const PlannerArgs& a, int i, int j, double value) {
+__device__ double phase_duration(const Gm& past, const Gm& cur, const Gm& des, const PlannerArgs& a, int i, int j, bool value,
+                                 double& remain) {
   double t_phase = 1;
   int b = i;
-  while (!row_zero(s, L.cur, i + 1) && s(L.cur + (i + 1) * 4 + j) == value) { i++; t_phase++; }
-  if (row_zero(s, L.cur, i + 1)) {
+  while (!rz(cur, i + 1) && gbit(cur, i + 1, j) == value) { i++; t_phase++; }
+  if (rz(cur, i + 1)) {
     int k = 0;
-    while (!row_zero(s, L.des, k) && s(L.des + k * 4 + j) == value) { k++; t_phase++; }
+    while (!rz(des, k) && gbit(des, k, j) == value) { k++; t_phase++; }
   }
-  s(L.remain) = t_phase;
-  while (b > 0 && s(L.cur + (b - 1) * 4 + j) == value) { b--; t_phase++; }
+  remain = t_phase;
+  while (b > 0 && gbit(cur, b - 1, j) == value) { b--; t_phase++; }
   if (b == 0) {
-    while (!row_zero(s, L.past, b) && s(L.past + b * 4 + j) == value) { b++; t_phase++; }
+    while (!rz(past, b) && gbit(past, b, j) == value) { b++; t_phase++; }
   }
   return t_phase * a.dt_mpc;
 }
 
-// Gait::updateGait = changeGait + rollGait (src/Gait.cpp:184-260)
-__device__ void gait_update(const PS& s, const Lay& L, const PlannerArgs& a, int k, const double* q7, int code) {
-  s(L.isstatic) = 0.0;
-  if (code >= 1 && code <= 5) create_desired(s, L, a, code);
-  if (code == 4) {
-    for (int i = 0; i < 7; i++) s(L.qstatic + i) = q7[i];
-    s(L.isstatic) = 1.0;
-  }
+// Gait::updateGait = changeGait + rollGait (src/Gait.cpp:184-260); returns whether the gait matrices were rolled
+__device__ void gait_update(Gm& past, Gm& cur, Gm& des, const PlannerArgs& a, int k, int code, double& newphase) {
+  if (code >= 1 && code <= 5) create_desired(des, a, code);
   if (k % a.k_mpc != 0) return;
-  for (int m = a.n_steps; m > 0; m--) row_swap(s, L.past, m, m - 1);
+  rot_down(past, a.n_steps + 1);
   bool differ = false;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    s(L.past + c) = s(L.cur + c);
-    differ = differ || (s(L.cur + c) != s(L.cur + 4 + c));
+    past.c[c] = (past.c[c] & ~1ull) | (cur.c[c] & 1ull);
+    differ = differ || ((cur.c[c] & 1ull) != ((cur.c[c] >> 1) & 1ull));
   }
-  s(L.newphase) = differ ? 1.0 : 0.0;
+  newphase = differ ? 1.0 : 0.0;
   int index = 1;
-  while (!row_zero(s, L.cur, index)) { row_swap(s, L.cur, index - 1, index); index++; }
+  while (!rz(cur, index)) index++;
+  rot_up(cur, index);
 #pragma unroll
-  for (int c = 0; c < 4; c++) s(L.cur + (index - 1) * 4 + c) = s(L.des + c);
+  for (int c = 0; c < 4; c++) cur.c[c] = (cur.c[c] & ~(1ull << (index - 1))) | ((des.c[c] & 1ull) << (index - 1));
   index = 1;
-  while (!row_zero(s, L.des, index)) { row_swap(s, L.des, index - 1, index); index++; }
+  while (!rz(des, index)) index++;
+  rot_up(des, index);
 }
 
 // pinocchio::rpy::matrixToRpy of the rotation of quaternion (x, y, z, w) [third-party definition restated]
@@ -185,8 +229,8 @@ __device__ void state_compute(const PlannerArgs& a, const double* q7, const doub
       x = vref6[0] * dtv;
       y = vref6[1] * dtv;
     }
-    X[0 * ld + 1 + i] = x + X[0 * ld];
-    X[1 * ld + 1 + i] = y + X[1 * ld];
+    X[0 * ld + 1 + i] = x + 0.0;
+    X[1 * ld + 1 + i] = y + 0.0;
     X[2 * ld + 1 + i] = a.h_ref + z_average;
     X[3 * ld + 1 + i] = 0.0;
     X[4 * ld + 1 + i] = 0.0;
@@ -201,123 +245,52 @@ __device__ void state_compute(const PlannerArgs& a, const double* q7, const doub
 
 #define FSI(i, r, c) (L.fs + ((i)*3 + (r)) * 4 + (c))
 
-// FootstepPlanner::updateFootsteps (src/FootstepPlanner.cpp:51-74) with computeTargetFootstep (:204-221),
-// computeFootsteps (:76-156), computeNextFootstep (:158-186), updateTargetFootsteps (:188-202), updateNewContact (:223-232)
-__device__ void footsteps_update(const PS& s, const Lay& L, const PlannerArgs& a, bool refresh, int k, const double* q7,
-                                 const double* b_v, const double* b_vref) {
-  const int Ng = a.N_gait;
-  if (refresh && s(L.newphase) != 0.0)
-    for (int i = 0; i < 4; i++)
-      if (s(L.cur + i) == 1.0)
-        for (int r = 0; r < 3; r++) s(L.cf + r * 4 + i) = s(FSI(1, r, i));
-  {
-    const double ry = a.dt_wbc * b_vref[5];
-    const double c = cos(ry), sn = sin(ry);
-    const double dpx = a.dt_wbc * b_vref[0], dpy = a.dt_wbc * b_vref[1];
-    for (int j = 0; j < 4; j++)
-      if (s(L.cur + j) == 1.0) {
-        const double x = s(L.cf + j) - dpx, y = s(L.cf + 4 + j) - dpy;
-        s(L.cf + j) = c * x + sn * y;
-        s(L.cf + 4 + j) = -sn * x + c * y;
-      }
-  }
-  for (int e = 0; e < Ng * 12; e++) s(L.fs + e) = 0.0;
-  for (int j = 0; j < 4; j++)
-    if (s(L.cur + j) == 1.0)
-      for (int r = 0; r < 3; r++) s(FSI(0, r, j)) = s(L.cf + r * 4 + j);
-  // running values of dt_cum / yaw / dx / dy for row i-1 (only consumed when a foot lands at row i)
-  const double w = b_vref[5];
-  double dtc_prev = a.dt_wbc * k;
-  const double cross0 = b_v[1] * b_vref[5] - b_v[2] * b_vref[4], cross1 = b_v[2] * b_vref[3] - b_v[0] * b_vref[5];
-  int i = 1;
-  while (!row_zero(s, L.cur, i)) {
-    for (int j = 0; j < 4; j++) {
-      const double gp = s(L.cur + (i - 1) * 4 + j), gc = s(L.cur + i * 4 + j);
-      if (gp * gc > 0) {
-        for (int r = 0; r < 3; r++) s(FSI(i, r, j)) = s(FSI(i - 1, r, j));
-      }
-    }
-    for (int j = 0; j < 4; j++) {
-      const double gp = s(L.cur + (i - 1) * 4 + j), gc = s(L.cur + i * 4 + j);
-      if ((1 - gp) * gc > 0) {
-        double dxp, dyp;
-        if (w != 0) {
-          dxp = (b_v[0] * sin(w * dtc_prev) + b_v[1] * (cos(w * dtc_prev) - 1.0)) / w;
-          dyp = (b_v[1] * sin(w * dtc_prev) - b_v[0] * (cos(w * dtc_prev) - 1.0)) / w;
-        } else {
-          dxp = b_v[0] * dtc_prev;
-          dyp = b_v[1] * dtc_prev;
-        }
-        const double t_stance = phase_duration(s, L, a, i, j, 1.0);
-        double nf[3];
-        const double cr[3] = {cross0, cross1, 0.0};
-        for (int r = 0; r < 3; r++) {
-          double v = t_stance * 0.5 * b_v[r];
-          v += a.k_feedback * (b_v[r] - b_vref[r]);
-          v += 0.5 * sqrt(a.h_ref / a.g) * cr[r];
-          nf[r] = v;
-        }
-        nf[0] = fmax(fmin(nf[0], a.L), -a.L);
-        nf[1] = fmax(fmin(nf[1], a.L), -a.L);
-        nf[0] += a.shoulders[0 * 4 + j];
-        nf[1] += a.shoulders[1 * 4 + j];
-        nf[2] = 0.0;
-        const double yawp = w * dtc_prev;
-        const double c = cos(yawp), sn = sin(yawp);
-        s(FSI(i, 0, j)) = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
-        s(FSI(i, 1, j)) = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
-        s(FSI(i, 2, j)) = (0.0 * nf[0] + 0.0 * nf[1] + 1.0 * nf[2]) + 0.0;
-      }
-    }
-    dtc_prev = dtc_prev + a.dt_mpc;  // dt_cum(i) = dt_cum(i-1) + dt for a non-zero row i
-    i++;
-  }
-  for (int f = 0; f < 4; f++) {
-    int index = 0;
-    while (index < Ng - 1 && s(FSI(index, 0, f)) == 0.0) index++;
-    s(L.tgt + f) = s(FSI(index, 0, f));
-    s(L.tgt + 4 + f) = s(FSI(index, 1, f));
-    s(L.tgt + 8 + f) = 0.0;
-  }
-  double rpy[3];
-  quat_to_rpy(q7 + 3, rpy);
-  const double c = cos(rpy[2]), sn = sin(rpy[2]);
-  for (int f = 0; f < 4; f++) {
-    const double x = s(L.tgt + f), y = s(L.tgt + 4 + f);
-    s(L.otgt + f) = (c * x - sn * y) + q7[0];
-    s(L.otgt + 4 + f) = (sn * x + c * y) + q7[1];
-  }
+// x^N by repeated multiplication in a fixed order (the reference's std::pow(x, n) with small integer n)
+template <int N>
+__device__ __forceinline__ double ipow(double x) {
+  double r = x;
+#pragma unroll
+  for (int i = 1; i < N; i++) r *= x;
+  return r;
 }
 
-// FootTrajectoryGenerator::updateFootPosition (src/FootTrajectoryGenerator.cpp:41-106)
-__device__ void update_foot_position(const PS& s, const Lay& L, const PlannerArgs& a, int j, const double tf[3]) {
-  const double ddx0 = s(L.acc + j), ddy0 = s(L.acc + 4 + j);
-  const double dx0 = s(L.vel + j), dy0 = s(L.vel + 4 + j);
-  const double x0 = s(L.pos + j), y0 = s(L.pos + 4 + j);
-  const double t = s(L.t0s + j), d = s(L.tsw + j), dt = a.dt_wbc;
-#define P(x_, n_) pow((x_), (n_))
+// Foot trajectory state of one instance in registers (statically indexed: loops over the four feet are unrolled)
+struct FootTraj {
+  double t0s[4], tsw[4], ax[6][4], ay[6][4], pos[3][4], vel[3][4], acc[3][4];
+};
+
+// FootTrajectoryGenerator::updateFootPosition (src/FootTrajectoryGenerator.cpp:41-106) for foot J
+template <int J>
+__device__ __forceinline__ void update_foot_position(FootTraj& f, const PS& s, const Lay& L, const PlannerArgs& a, const double tf[3]) {
+  constexpr int j = J;
+  const double ddx0 = f.acc[0][j], ddy0 = f.acc[1][j];
+  const double dx0 = f.vel[0][j], dy0 = f.vel[1][j];
+  const double x0 = f.pos[0][j], y0 = f.pos[1][j];
+  const double t = f.t0s[j], d = f.tsw[j], dt = a.dt_wbc;
+#define P(x_, n_) ipow<n_>(x_)
   if (t < d - a.lock_time) {
     const double den1 = (2 * P((t - d), 2) * (P(t, 3) - 3 * P(t, 2) * d + 3 * t * P(d, 2) - P(d, 3)));
     const double den2 = (2 * (P(t, 2) - 2 * t * d + P(d, 2)) * (P(t, 3) - 3 * P(t, 2) * d + 3 * t * P(d, 2) - P(d, 3)));
+#pragma unroll
     for (int ax = 0; ax < 2; ax++) {
       const double dd0 = ax ? ddy0 : ddx0, d0 = ax ? dy0 : dx0, p0 = ax ? y0 : x0, tg = tf[ax];
-      const int A = ax ? L.ay : L.ax;
-      s(A + 0 * 4 + j) = (dd0 * P(t, 2) - 2 * dd0 * t * d - 6 * d0 * t + dd0 * P(d, 2) + 6 * d0 * d + 12 * p0 - 12 * tg) / den1;
-      s(A + 1 * 4 + j) = (30 * t * tg - 30 * t * p0 - 30 * d * p0 + 30 * d * tg - 2 * P(t, 3) * dd0 - 3 * P(d, 3) * dd0 +
-                          14 * P(t, 2) * d0 - 16 * P(d, 2) * d0 + 2 * t * d * d0 + 4 * t * P(d, 2) * dd0 + P(t, 2) * d * dd0) / den1;
-      s(A + 2 * 4 + j) = (P(t, 4) * dd0 + 3 * P(d, 4) * dd0 - 8 * P(t, 3) * d0 + 12 * P(d, 3) * d0 + 20 * P(t, 2) * p0 -
-                          20 * P(t, 2) * tg + 20 * P(d, 2) * p0 - 20 * P(d, 2) * tg + 80 * t * d * p0 - 80 * t * d * tg +
-                          4 * P(t, 3) * d * dd0 + 28 * t * P(d, 2) * d0 - 32 * P(t, 2) * d * d0 - 8 * P(t, 2) * P(d, 2) * dd0) / den1;
-      s(A + 3 * 4 + j) = -(P(d, 5) * dd0 + 4 * t * P(d, 4) * dd0 + 3 * P(t, 4) * d * dd0 + 36 * t * P(d, 3) * d0 -
-                           24 * P(t, 3) * d * d0 + 60 * t * P(d, 2) * p0 + 60 * P(t, 2) * d * p0 - 60 * t * P(d, 2) * tg -
-                           60 * P(t, 2) * d * tg - 8 * P(t, 2) * P(d, 3) * dd0 - 12 * P(t, 2) * P(d, 2) * d0) / den2;
-      s(A + 4 * 4 + j) = -(2 * P(d, 5) * d0 - 2 * t * P(d, 5) * dd0 - 10 * t * P(d, 4) * d0 + P(t, 2) * P(d, 4) * dd0 +
-                           4 * P(t, 3) * P(d, 3) * dd0 - 3 * P(t, 4) * P(d, 2) * dd0 - 16 * P(t, 2) * P(d, 3) * d0 +
-                           24 * P(t, 3) * P(d, 2) * d0 - 60 * P(t, 2) * P(d, 2) * p0 + 60 * P(t, 2) * P(d, 2) * tg) / den1;
-      s(A + 5 * 4 + j) = (2 * tg * P(t, 5) - dd0 * P(t, 4) * P(d, 3) - 10 * tg * P(t, 4) * d + 2 * dd0 * P(t, 3) * P(d, 4) +
-                          8 * d0 * P(t, 3) * P(d, 3) + 20 * tg * P(t, 3) * P(d, 2) - dd0 * P(t, 2) * P(d, 5) -
-                          10 * d0 * P(t, 2) * P(d, 4) - 20 * p0 * P(t, 2) * P(d, 3) + 2 * d0 * t * P(d, 5) +
-                          10 * p0 * t * P(d, 4) - 2 * p0 * P(d, 5)) / den2;
+      double(&A)[6][4] = ax ? f.ay : f.ax;
+      A[0][j] = (dd0 * P(t, 2) - 2 * dd0 * t * d - 6 * d0 * t + dd0 * P(d, 2) + 6 * d0 * d + 12 * p0 - 12 * tg) / den1;
+      A[1][j] = (30 * t * tg - 30 * t * p0 - 30 * d * p0 + 30 * d * tg - 2 * P(t, 3) * dd0 - 3 * P(d, 3) * dd0 +
+                 14 * P(t, 2) * d0 - 16 * P(d, 2) * d0 + 2 * t * d * d0 + 4 * t * P(d, 2) * dd0 + P(t, 2) * d * dd0) / den1;
+      A[2][j] = (P(t, 4) * dd0 + 3 * P(d, 4) * dd0 - 8 * P(t, 3) * d0 + 12 * P(d, 3) * d0 + 20 * P(t, 2) * p0 -
+                 20 * P(t, 2) * tg + 20 * P(d, 2) * p0 - 20 * P(d, 2) * tg + 80 * t * d * p0 - 80 * t * d * tg +
+                 4 * P(t, 3) * d * dd0 + 28 * t * P(d, 2) * d0 - 32 * P(t, 2) * d * d0 - 8 * P(t, 2) * P(d, 2) * dd0) / den1;
+      A[3][j] = -(P(d, 5) * dd0 + 4 * t * P(d, 4) * dd0 + 3 * P(t, 4) * d * dd0 + 36 * t * P(d, 3) * d0 -
+                  24 * P(t, 3) * d * d0 + 60 * t * P(d, 2) * p0 + 60 * P(t, 2) * d * p0 - 60 * t * P(d, 2) * tg -
+                  60 * P(t, 2) * d * tg - 8 * P(t, 2) * P(d, 3) * dd0 - 12 * P(t, 2) * P(d, 2) * d0) / den2;
+      A[4][j] = -(2 * P(d, 5) * d0 - 2 * t * P(d, 5) * dd0 - 10 * t * P(d, 4) * d0 + P(t, 2) * P(d, 4) * dd0 +
+                  4 * P(t, 3) * P(d, 3) * dd0 - 3 * P(t, 4) * P(d, 2) * dd0 - 16 * P(t, 2) * P(d, 3) * d0 +
+                  24 * P(t, 3) * P(d, 2) * d0 - 60 * P(t, 2) * P(d, 2) * p0 + 60 * P(t, 2) * P(d, 2) * tg) / den1;
+      A[5][j] = (2 * tg * P(t, 5) - dd0 * P(t, 4) * P(d, 3) - 10 * tg * P(t, 4) * d + 2 * dd0 * P(t, 3) * P(d, 4) +
+                 8 * d0 * P(t, 3) * P(d, 3) + 20 * tg * P(t, 3) * P(d, 2) - dd0 * P(t, 2) * P(d, 5) -
+                 10 * d0 * P(t, 2) * P(d, 4) - 20 * p0 * P(t, 2) * P(d, 3) + 2 * d0 * t * P(d, 5) +
+                 10 * p0 * t * P(d, 4) - 2 * p0 * P(d, 5)) / den2;
     }
     s(L.fttgt + j) = tf[0];
     s(L.fttgt + 4 + j) = tf[1];
@@ -327,76 +300,82 @@ __device__ void update_foot_position(const PS& s, const Lay& L, const PlannerArg
                Az3 = (P(d, 3) * a.max_height) / dz;
   const double ev = t + dt;
   if (t < 0.0 || t > d) {
-    s(L.pos + j) = x0; s(L.pos + 4 + j) = y0;
-    s(L.vel + j) = 0.0; s(L.vel + 4 + j) = 0.0;
-    s(L.acc + j) = 0.0; s(L.acc + 4 + j) = 0.0;
+    f.pos[0][j] = x0; f.pos[1][j] = y0;
+    f.vel[0][j] = 0.0; f.vel[1][j] = 0.0;
+    f.acc[0][j] = 0.0; f.acc[1][j] = 0.0;
   } else {
+#pragma unroll
     for (int ax = 0; ax < 2; ax++) {
-      const int A = ax ? L.ay : L.ax;
-      const double A0 = s(A + j), A1 = s(A + 4 + j), A2 = s(A + 8 + j), A3 = s(A + 12 + j), A4 = s(A + 16 + j), A5 = s(A + 20 + j);
-      s(L.pos + ax * 4 + j) = A5 + A4 * ev + A3 * P(ev, 2) + A2 * P(ev, 3) + A1 * P(ev, 4) + A0 * P(ev, 5);
-      s(L.vel + ax * 4 + j) = A4 + 2 * A3 * ev + 3 * A2 * P(ev, 2) + 4 * A1 * P(ev, 3) + 5 * A0 * P(ev, 4);
-      s(L.acc + ax * 4 + j) = 2 * A3 + 3 * 2 * A2 * ev + 4 * 3 * A1 * P(ev, 2) + 5 * 4 * A0 * P(ev, 3);
+      double(&A)[6][4] = ax ? f.ay : f.ax;
+      const double A0 = A[0][j], A1 = A[1][j], A2 = A[2][j], A3 = A[3][j], A4 = A[4][j], A5 = A[5][j];
+      f.pos[ax][j] = A5 + A4 * ev + A3 * P(ev, 2) + A2 * P(ev, 3) + A1 * P(ev, 4) + A0 * P(ev, 5);
+      f.vel[ax][j] = A4 + 2 * A3 * ev + 3 * A2 * P(ev, 2) + 4 * A1 * P(ev, 3) + 5 * A0 * P(ev, 4);
+      f.acc[ax][j] = 2 * A3 + 3 * 2 * A2 * ev + 4 * 3 * A1 * P(ev, 2) + 5 * 4 * A0 * P(ev, 3);
     }
   }
-  s(L.vel + 8 + j) = 3 * Az3 * P(ev, 2) + 4 * Az2 * P(ev, 3) + 5 * Az1 * P(ev, 4) + 6 * Az0 * P(ev, 5);
-  s(L.acc + 8 + j) = 2 * 3 * Az3 * ev + 3 * 4 * Az2 * P(ev, 2) + 4 * 5 * Az1 * P(ev, 3) + 5 * 6 * Az0 * P(ev, 4);
-  s(L.pos + 8 + j) = Az3 * P(ev, 3) + Az2 * P(ev, 4) + Az1 * P(ev, 5) + Az0 * P(ev, 6);
+  f.vel[2][j] = 3 * Az3 * P(ev, 2) + 4 * Az2 * P(ev, 3) + 5 * Az1 * P(ev, 4) + 6 * Az0 * P(ev, 5);
+  f.acc[2][j] = 2 * 3 * Az3 * ev + 3 * 4 * Az2 * P(ev, 2) + 4 * 5 * Az1 * P(ev, 3) + 5 * 6 * Az0 * P(ev, 4);
+  f.pos[2][j] = Az3 * P(ev, 3) + Az2 * P(ev, 4) + Az1 * P(ev, 5) + Az0 * P(ev, 6);
 #undef P
 }
 
-// FootTrajectoryGenerator::update (src/FootTrajectoryGenerator.cpp:108-151)
-__device__ void traj_update(const PS& s, const Lay& L, const PlannerArgs& a, int k, const double tgt[12]) {
-  if ((k % a.k_mpc) == 0) {
-    int nf = 0;
-    for (int i = 0; i < 4; i++)
-      if (s(L.cur + i) == 0.0) { s(L.feet + nf) = (double)i; nf++; }
-    s(L.nfeet) = (double)nf;
-    if (nf == 0) return;
-    for (int jj = 0; jj < nf; jj++) {
-      const int i = (int)s(L.feet + jj);
-      const double tsw = phase_duration(s, L, a, 0, i, 0.0);
-      s(L.tsw + i) = tsw;
-      const double value = tsw - (s(L.remain) * a.k_mpc - ((k + 1) % a.k_mpc)) * a.dt_wbc - a.dt_wbc;
-      s(L.t0s + i) = fmax(0.0, value);
-    }
-  } else {
-    const int nf = (int)s(L.nfeet);
-    if (nf == 0) return;
-    for (int jj = 0; jj < nf; jj++) {
-      const int i = (int)s(L.feet + jj);
-      s(L.t0s + i) = fmax(0.0, s(L.t0s + i) + a.dt_wbc);
-    }
+__device__ void traj_load(FootTraj& f, const PS& s, const Lay& L) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    f.t0s[j] = s(L.t0s + j); f.tsw[j] = s(L.tsw + j);
+#pragma unroll
+    for (int r = 0; r < 6; r++) { f.ax[r][j] = s(L.ax + r * 4 + j); f.ay[r][j] = s(L.ay + r * 4 + j); }
+#pragma unroll
+    for (int r = 0; r < 3; r++) { f.pos[r][j] = s(L.pos + r * 4 + j); f.vel[r][j] = s(L.vel + r * 4 + j); f.acc[r][j] = s(L.acc + r * 4 + j); }
   }
-  const int nf = (int)s(L.nfeet);
-  for (int jj = 0; jj < nf; jj++) {
-    const int i = (int)s(L.feet + jj);
-    const double tf[3] = {tgt[i], tgt[4 + i], tgt[8 + i]};
-    update_foot_position(s, L, a, i, tf);
+}
+__device__ void traj_store(const FootTraj& f, const PS& s, const Lay& L) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    s(L.t0s + j) = f.t0s[j]; s(L.tsw + j) = f.tsw[j];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { s(L.ax + r * 4 + j) = f.ax[r][j]; s(L.ay + r * 4 + j) = f.ay[r][j]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) { s(L.pos + r * 4 + j) = f.pos[r][j]; s(L.vel + r * 4 + j) = f.vel[r][j]; s(L.acc + r * 4 + j) = f.acc[r][j]; }
   }
 }
 
 }  // namespace
 
+// One thread per instance; see the note above on the register representation.
 __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
   const Lay L = make_layout(a.N_gait);
+  const int Ng = a.N_gait;
   PS s;
   s.base = a.ps + b;
   s.stride = (size_t)a.B;
 
-  if (a.mode & kPlanInit) {
-    gait_init(s, L, a);
+  Gm past, cur, des;
+  double newphase = 0.0, remain = 0.0;
+  const bool init = (a.mode & kPlanInit) != 0;
+  const bool uses_gait = (a.mode & (kPlanGait | kPlanFootsteps | kPlanTraj | kPlanOutputs)) != 0;
+  if (init) {
+    gait_init(past, cur, des, a);
     for (int e = 0; e < 12; e++) {
       s(L.cf + e) = a.shoulders[e]; s(L.tgt + e) = a.shoulders[e]; s(L.otgt + e) = a.shoulders[e];
       s(L.fttgt + e) = a.init_target[e]; s(L.pos + e) = a.init_pos[e]; s(L.vel + e) = 0.0; s(L.acc + e) = 0.0;
     }
-    for (int e = 0; e < a.N_gait * 12; e++) s(L.fs + e) = 0.0;
+    for (int e = 0; e < Ng * 12; e++) s(L.fs + e) = 0.0;
     for (int e = 0; e < 24; e++) { s(L.ax + e) = 0.0; s(L.ay + e) = 0.0; }
     for (int e = 0; e < 4; e++) { s(L.t0s + e) = 0.0; s(L.tsw + e) = 0.0; s(L.feet + e) = 0.0; }
     for (int e = 0; e < 7; e++) s(L.qstatic + e) = 0.0;
+    s(L.newphase) = 0.0; s(L.isstatic) = 0.0; s(L.remain) = 0.0; s(L.nfeet) = 0.0;
+  } else if (uses_gait) {
+    gm_load(s, L.past, Ng, past);
+    gm_load(s, L.cur, Ng, cur);
+    gm_load(s, L.des, Ng, des);
+    newphase = s(L.newphase);
+    remain = s(L.remain);
   }
+  bool gait_dirty = init, remain_dirty = false;
+
   double q7[7] = {0, 0, 0, 0, 0, 0, 1}, hv[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
   if (a.q7) for (int i = 0; i < 7; i++) q7[i] = a.q7[(size_t)b * 7 + i];
   if (a.hv) for (int i = 0; i < 6; i++) hv[i] = a.hv[(size_t)b * 6 + i];
@@ -404,34 +383,228 @@ __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
   const int code = a.code ? a.code[b] : a.code_scalar;
   const int k = a.k;
 
-  if (a.mode & kPlanGait) gait_update(s, L, a, k, q7, code);
-  if (a.mode & kPlanFootsteps) footsteps_update(s, L, a, a.refresh != 0, a.k_footsteps, q7, hv, vr);
-  if (a.mode & kPlanTraj) {
-    double tgt[12];
-    for (int e = 0; e < 12; e++) tgt[e] = a.target_in ? a.target_in[(size_t)b * 12 + e] : s(L.otgt + e);
-    traj_update(s, L, a, k, tgt);
+  // ---- Gait::updateGait
+  if (a.mode & kPlanGait) {
+    s(L.isstatic) = (code == 4) ? 1.0 : 0.0;
+    if (code == 4)
+      for (int i = 0; i < 7; i++) s(L.qstatic + i) = q7[i];
+    gait_update(past, cur, des, a, k, code, newphase);
+    if (k % a.k_mpc == 0) s(L.newphase) = newphase;
+    gait_dirty = true;
   }
-  if ((a.mode & kPlanState) && a.xref) state_compute(a, q7, hv, vr, a.z_average, a.xref + (size_t)b * 12 * (a.n_steps + 1));
 
-  // ---- outputs in the layouts the solver kernels read
-  if (a.fsteps && (a.mode & (kPlanFootsteps | kPlanOutputs))) {  // FootstepPlanner::getFootsteps / vectorToMatrix (:235-249)
-    double* o = a.fsteps + (size_t)b * a.N_gait * 12;
-    for (int i = 0; i < a.N_gait; i++)
+  // ---- FootstepPlanner::updateFootsteps (src/FootstepPlanner.cpp:51-74) with computeTargetFootstep (:204-221),
+  // computeFootsteps (:76-156), computeNextFootstep (:158-186), updateTargetFootsteps (:188-202), updateNewContact (:223-232)
+  double otgt[12];
+  bool have_otgt = false;
+  if (a.mode & kPlanFootsteps) {
+    const double* b_v = hv;
+    const double* b_vref = vr;
+    double cf[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) cf[r][j] = s(L.cf + r * 4 + j);
+    if (a.refresh != 0 && newphase != 0.0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (gbit(cur, 0, j)) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) cf[r][j] = s(FSI(1, r, j));
+        }
+    }
+    {
+      const double ry = a.dt_wbc * b_vref[5];
+      const double c = cos(ry), sn = sin(ry);
+      const double dpx = a.dt_wbc * b_vref[0], dpy = a.dt_wbc * b_vref[1];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (gbit(cur, 0, j)) {
+          const double x = cf[0][j] - dpx, y = cf[1][j] - dpy;
+          cf[0][j] = c * x + sn * y;
+          cf[1][j] = -sn * x + c * y;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) s(L.cf + r * 4 + j) = cf[r][j];
+    // the table, row by row: `row` is row i-1 while row i is being built
+    double row[3][4], tg[2][4];
+    bool found[4] = {false, false, false, false};
+    double* fo = (a.fsteps) ? a.fsteps + (size_t)b * Ng * 12 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) row[r][j] = gbit(cur, 0, j) ? cf[r][j] : 0.0;
+    const double w = b_vref[5];
+    double dtc_prev = a.dt_wbc * a.k_footsteps;
+    const double cross0 = b_v[1] * b_vref[5] - b_v[2] * b_vref[4], cross1 = b_v[2] * b_vref[3] - b_v[0] * b_vref[5];
+    bool live = true;  // rows up to the first all-zero gait row are built, the rest of the table is zero
+    for (int i = 0; i < Ng; i++) {
+      if (i > 0) {
+        live = live && !rz(cur, i);
+        double nrow[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool gp = gbit(cur, i - 1, j), gc = gbit(cur, i, j);
+#pragma unroll
+          for (int r = 0; r < 3; r++) nrow[r][j] = (live && gp && gc) ? row[r][j] : 0.0;
+        }
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool gp = gbit(cur, i - 1, j), gc = gbit(cur, i, j);
+            if (!gp && gc) {
+              double dxp, dyp;
+              if (w != 0) {
+                dxp = (b_v[0] * sin(w * dtc_prev) + b_v[1] * (cos(w * dtc_prev) - 1.0)) / w;
+                dyp = (b_v[1] * sin(w * dtc_prev) - b_v[0] * (cos(w * dtc_prev) - 1.0)) / w;
+              } else {
+                dxp = b_v[0] * dtc_prev;
+                dyp = b_v[1] * dtc_prev;
+              }
+              const double t_stance = phase_duration(past, cur, des, a, i, j, true, remain);
+              remain_dirty = true;
+              double nf[3];
+              const double cr[3] = {cross0, cross1, 0.0};
+#pragma unroll
+              for (int r = 0; r < 3; r++) {
+                double v = t_stance * 0.5 * b_v[r];
+                v += a.k_feedback * (b_v[r] - b_vref[r]);
+                v += 0.5 * sqrt(a.h_ref / a.g) * cr[r];
+                nf[r] = v;
+              }
+              nf[0] = fmax(fmin(nf[0], a.L), -a.L);
+              nf[1] = fmax(fmin(nf[1], a.L), -a.L);
+              nf[0] += a.shoulders[0 * 4 + j];
+              nf[1] += a.shoulders[1 * 4 + j];
+              nf[2] = 0.0;
+              const double yawp = w * dtc_prev;
+              const double c = cos(yawp), sn = sin(yawp);
+              nrow[0][j] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
+              nrow[1][j] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
+              nrow[2][j] = (0.0 * nf[0] + 0.0 * nf[1] + 1.0 * nf[2]) + 0.0;
+            }
+          }
+          dtc_prev = dtc_prev + a.dt_mpc;  // dt_cum(i) = dt_cum(i-1) + dt for a non-zero row i
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 3; r++) row[r][j] = nrow[r][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          s(FSI(i, r, j)) = row[r][j];
+          if (fo) fo[i * 12 + 3 * j + r] = row[r][j];  // FootstepPlanner::getFootsteps / vectorToMatrix (:235-249)
+        }
+        if (!found[j] && (row[0][j] != 0.0 || i == Ng - 1)) {  // updateTargetFootsteps: first row with x != 0
+          found[j] = true;
+          tg[0][j] = row[0][j];
+          tg[1][j] = row[1][j];
+        }
+      }
+    }
+    double rpy[3];
+    quat_to_rpy(q7 + 3, rpy);
+    const double c = cos(rpy[2]), sn = sin(rpy[2]);
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      s(L.tgt + f) = tg[0][f];
+      s(L.tgt + 4 + f) = tg[1][f];
+      s(L.tgt + 8 + f) = 0.0;
+      otgt[f] = (c * tg[0][f] - sn * tg[1][f]) + q7[0];
+      otgt[4 + f] = (sn * tg[0][f] + c * tg[1][f]) + q7[1];
+      s(L.otgt + f) = otgt[f];
+      s(L.otgt + 4 + f) = otgt[4 + f];
+    }
+#pragma unroll
+    for (int f = 0; f < 4; f++) otgt[8 + f] = s(L.otgt + 8 + f);
+    have_otgt = true;
+  } else if (a.fsteps && (a.mode & kPlanOutputs)) {
+    double* o = a.fsteps + (size_t)b * Ng * 12;
+    for (int i = 0; i < Ng; i++)
       for (int j = 0; j < 4; j++)
         for (int r = 0; r < 3; r++) o[i * 12 + 3 * j + r] = s(FSI(i, r, j));
   }
-  if (a.gait && (a.mode & (kPlanGait | kPlanOutputs))) {
-    double* o = a.gait + (size_t)b * a.N_gait * 4;
-    for (int e = 0; e < a.N_gait * 4; e++) o[e] = s(L.cur + e);
-  }
-  if (a.target && (a.mode & (kPlanFootsteps | kPlanOutputs)))
-    for (int e = 0; e < 12; e++) a.target[(size_t)b * 12 + e] = s(L.otgt + e);
-  if (a.feet_pva && (a.mode & (kPlanTraj | kPlanOutputs)))
+
+  // ---- FootTrajectoryGenerator::update (src/FootTrajectoryGenerator.cpp:108-151)
+  if (a.mode & kPlanTraj) {
+    double tgt[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) tgt[e] = a.target_in ? a.target_in[(size_t)b * 12 + e] : (have_otgt ? otgt[e] : s(L.otgt + e));
+    FootTraj f;
+    traj_load(f, s, L);
+    unsigned swing = 0;
+    bool run = true;
+    if ((k % a.k_mpc) == 0) {
+      int nf = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!gbit(cur, 0, i)) { s(L.feet + nf) = (double)i; nf++; swing |= 1u << i; }
+      s(L.nfeet) = (double)nf;
+      run = nf != 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (swing & (1u << i)) {
+          const double tsw = phase_duration(past, cur, des, a, 0, i, false, remain);
+          remain_dirty = true;
+          f.tsw[i] = tsw;
+          const double value = tsw - (remain * a.k_mpc - ((k + 1) % a.k_mpc)) * a.dt_wbc - a.dt_wbc;
+          f.t0s[i] = fmax(0.0, value);
+        }
+    } else {
+      const int nf = (int)s(L.nfeet);
+      run = nf != 0;
+      for (int jj = 0; jj < nf; jj++) swing |= 1u << (int)s(L.feet + jj);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (swing & (1u << i)) f.t0s[i] = fmax(0.0, f.t0s[i] + a.dt_wbc);
+    }
+    if (run) {
+      if (swing & 1u) { const double tf[3] = {tgt[0], tgt[4], tgt[8]}; update_foot_position<0>(f, s, L, a, tf); }
+      if (swing & 2u) { const double tf[3] = {tgt[1], tgt[5], tgt[9]}; update_foot_position<1>(f, s, L, a, tf); }
+      if (swing & 4u) { const double tf[3] = {tgt[2], tgt[6], tgt[10]}; update_foot_position<2>(f, s, L, a, tf); }
+      if (swing & 8u) { const double tf[3] = {tgt[3], tgt[7], tgt[11]}; update_foot_position<3>(f, s, L, a, tf); }
+    }
+    traj_store(f, s, L);
+    if (a.feet_pva) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          a.feet_pva[(size_t)b * 36 + r * 4 + j] = f.pos[r][j];
+          a.feet_pva[(size_t)b * 36 + 12 + r * 4 + j] = f.vel[r][j];
+          a.feet_pva[(size_t)b * 36 + 24 + r * 4 + j] = f.acc[r][j];
+        }
+    }
+  } else if (a.feet_pva && (a.mode & kPlanOutputs)) {
     for (int e = 0; e < 12; e++) {
       a.feet_pva[(size_t)b * 36 + e] = s(L.pos + e);
       a.feet_pva[(size_t)b * 36 + 12 + e] = s(L.vel + e);
       a.feet_pva[(size_t)b * 36 + 24 + e] = s(L.acc + e);
     }
+  }
+  if ((a.mode & kPlanState) && a.xref) state_compute(a, q7, hv, vr, a.z_average, a.xref + (size_t)b * 12 * (a.n_steps + 1));
+
+  // ---- remaining outputs / state
+  if (a.gait && (a.mode & (kPlanGait | kPlanOutputs))) {
+    double* o = a.gait + (size_t)b * Ng * 4;
+    for (int i = 0; i < Ng; i++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) o[i * 4 + c] = gbit(cur, i, c) ? 1.0 : 0.0;
+  }
+  if (a.target && (a.mode & (kPlanFootsteps | kPlanOutputs)))
+    for (int e = 0; e < 12; e++) a.target[(size_t)b * 12 + e] = have_otgt ? otgt[e] : s(L.otgt + e);
+  if (gait_dirty) {
+    gm_store(s, L.past, Ng, past);
+    gm_store(s, L.cur, Ng, cur);
+    gm_store(s, L.des, Ng, des);
+  }
+  if (remain_dirty) s(L.remain) = remain;
 }
 #undef FSI
 
