@@ -152,13 +152,16 @@ int qrw_planner_init(qrw_handle h, const qrw_planner_config *pc, void *stream);
  * Gait::updateGait(k, k_mpc, q, code) (src/Gait.cpp:184-192), FootstepPlanner::updateFootsteps(k % k_mpc == 0 && k != 0,
  * k_mpc - k % k_mpc, q, b_v, b_vref) (src/FootstepPlanner.cpp:51), FootTrajectoryGenerator::update(k, o_target)
  * (src/FootTrajectoryGenerator.cpp:108), StatePlanner::computeReferenceStates(q, v, vref, 0) (src/StatePlanner.cpp:21).
- *   in : d_q7 [B][7] (position, quaternion xyzw), d_hv [B][6], d_vref [B][6], d_code [B] int32 joystick codes or NULL
- *        (code_scalar then applies; 1 pacing, 2 bounding, 3 trot, 4 static as src/Gait.cpp:194-219; 5 walk)
+ *   in : d_q7 [B][q_ld] of which the first 7 entries of a row are read (position, quaternion xyzw; q_ld = 7, or 19 to
+ *        pass the q [B][19] of qrw_controller_update_state directly), d_hv [B][6], d_vref [B][6], d_code [B] int32
+ *        joystick codes or NULL (code_scalar then applies; 1 pacing, 2 bounding, 3 trot, 4 static as
+ *        src/Gait.cpp:194-219; 5 walk)
  *   out: d_xref [B][12][N+1], d_fsteps [B][N_gait][12], d_gait [B][N_gait][4] (current gait), d_target [B][3][4]
- *        (o_targetFootstep), d_feet_pva [B][3][3][4] (foot position, velocity, acceleration goals); any may be NULL */
-int qrw_planner_step(qrw_handle h, int32_t k, const double *d_q7, const double *d_hv, const double *d_vref,
+ *        (o_targetFootstep), d_feet_pva [B][3][3][4] (foot position, velocity, acceleration goals), d_contacts [B][4]
+ *        (row 0 of the current gait = the `contacts` operand of qrw_wbc_compute); any may be NULL */
+int qrw_planner_step(qrw_handle h, int32_t k, const double *d_q7, int32_t q_ld, const double *d_hv, const double *d_vref,
                      const int32_t *d_code, int32_t code_scalar, double *d_xref, double *d_fsteps, double *d_gait,
-                     double *d_target, double *d_feet_pva, void *stream);
+                     double *d_target, double *d_feet_pva, double *d_contacts, void *stream);
 
 /* One planner method at a time with host buffers (backs the bound-class drop-ins Gait / FootstepPlanner /
  * FootTrajectoryGenerator / StatePlanner, python/gepadd.cpp:44-181). mode is a bit set: 2 Gait::updateGait,

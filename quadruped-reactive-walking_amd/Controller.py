@@ -121,8 +121,7 @@ class Controller_batch:
     def _compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code):
         b, k = self._b, self.k
         self._st = st = b.controller_update_state(joy_v_ref, q_filt, v_filt, rpy, out=self._st)
-        self._plan = plan = b.planner_step(k, st["q"][:, :7].contiguous(), st["h_v"], st["v_ref"], joystick_code,
-                                           out=self._plan)
+        self._plan = plan = b.planner_step(k, st["q"], st["h_v"], st["v_ref"], joystick_code, out=self._plan)
         if (k % self.k_mpc) == 0:
             if self.multiprocessing:
                 self._solve_async(plan, k)
@@ -137,8 +136,8 @@ class Controller_batch:
             self.x_f_mpc = self._mpc_default
         self._wi = wi = b.controller_wbc_inputs(self.x_f_mpc, plan["xref"], plan["feet_pva"], st["v"], out=self._wi)
         fc = wi["feet_cmd"]
-        self._wbc = w = b.wbc_compute(wi["q_wbc"], wi["b_v"], wi["f_cmd"], plan["gait"][:, 0, :].contiguous(),
-                                      fc[0], fc[1], fc[2], out=self._wbc)
+        self._wbc = w = b.wbc_compute(wi["q_wbc"], wi["b_v"], wi["f_cmd"], plan["contacts"], fc[0], fc[1], fc[2],
+                                      out=self._wbc)
         self._res = b.controller_result(w["tau_ff"], w["qdes"], w["vdes"], q_filt, v_secu, out=self._res)
         self.result = Result(self._res["result"])
         self.error_flag = self._res["error_flag"]

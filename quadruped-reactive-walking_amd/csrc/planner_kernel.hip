@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
   bool gait_dirty = init, remain_dirty = false;
 
   double q7[7] = {0, 0, 0, 0, 0, 0, 1}, hv[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
-  if (a.q7) for (int i = 0; i < 7; i++) q7[i] = a.q7[(size_t)b * 7 + i];
+  if (a.q7) for (int i = 0; i < 7; i++) q7[i] = a.q7[(size_t)b * a.q_ld + i];
   if (a.hv) for (int i = 0; i < 6; i++) hv[i] = a.hv[(size_t)b * 6 + i];
   if (a.vref) for (int i = 0; i < 6; i++) vr[i] = a.vref[(size_t)b * 6 + i];
   const int code = a.code ? a.code[b] : a.code_scalar;
@@ -597,6 +597,9 @@ __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; c++) o[i * 4 + c] = gbit(cur, i, c) ? 1.0 : 0.0;
   }
+  if (a.contacts && uses_gait)
+#pragma unroll
+    for (int c = 0; c < 4; c++) a.contacts[(size_t)b * 4 + c] = gbit(cur, 0, c) ? 1.0 : 0.0;
   if (a.target && (a.mode & (kPlanFootsteps | kPlanOutputs)))
     for (int e = 0; e < 12; e++) a.target[(size_t)b * 12 + e] = have_otgt ? otgt[e] : s(L.otgt + e);
   if (gait_dirty) {

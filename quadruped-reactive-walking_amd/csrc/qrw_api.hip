@@ -444,6 +444,7 @@ static void planner_common(qrw_handle h, qrw::PlannerArgs& a) {
   a.max_height = h->pcfg.max_height; a.lock_time = h->pcfg.lock_time;
   for (int i = 0; i < 12; i++) { a.shoulders[i] = h->pcfg.shoulders[i]; a.init_target[i] = h->pcfg.init_target[i]; a.init_pos[i] = h->pcfg.init_foot_pos[i]; }
   a.ps = h->plan_st;
+  a.q_ld = 7;
 }
 
 extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void* stream) {
@@ -462,19 +463,22 @@ extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void
   return 0;
 }
 
-extern "C" int qrw_planner_step(qrw_handle h, int32_t k, const double* d_q7, const double* d_hv, const double* d_vref,
-                                const int32_t* d_code, int32_t code_scalar, double* d_xref, double* d_fsteps,
-                                double* d_gait, double* d_target, double* d_feet_pva, void* stream) {
+extern "C" int qrw_planner_step(qrw_handle h, int32_t k, const double* d_q7, int32_t q_ld, const double* d_hv,
+                                const double* d_vref, const int32_t* d_code, int32_t code_scalar, double* d_xref,
+                                double* d_fsteps, double* d_gait, double* d_target, double* d_feet_pva,
+                                double* d_contacts, void* stream) {
   if (!h || !h->plan_ready) return fail(-1, "qrw_planner_step: planner not initialised");
   if (!d_q7 || !d_hv || !d_vref) return fail(-1, "qrw_planner_step: null input");
+  if (q_ld < 7) return fail(-1, "qrw_planner_step: q_ld must be at least 7");
   qrw::PlannerArgs a;
   planner_common(h, a);
   a.mode = qrw::kPlanGait | qrw::kPlanFootsteps | qrw::kPlanTraj | qrw::kPlanState;
   a.k = k;
   a.refresh = ((k % a.k_mpc) == 0 && k != 0) ? 1 : 0;     // scripts/Controller.py:225
   a.k_footsteps = a.k_mpc - k % a.k_mpc;                  // scripts/Controller.py:226
-  a.q7 = d_q7; a.hv = d_hv; a.vref = d_vref; a.code = d_code; a.code_scalar = code_scalar;
+  a.q7 = d_q7; a.q_ld = q_ld; a.hv = d_hv; a.vref = d_vref; a.code = d_code; a.code_scalar = code_scalar;
   a.xref = d_xref; a.fsteps = d_fsteps; a.gait = d_gait; a.target = d_target; a.feet_pva = d_feet_pva;
+  a.contacts = d_contacts;
   if (qrw::planner_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_planner_step: launch failed", hipGetLastError());
   return 0;
 }

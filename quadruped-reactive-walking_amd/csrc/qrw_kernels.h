@@ -99,13 +99,13 @@ int mfma_selftest(double* max_err);
 // ---- planners (planner_kernel.hip)
 enum PlannerMode { kPlanInit = 1, kPlanGait = 2, kPlanFootsteps = 4, kPlanTraj = 8, kPlanState = 16, kPlanOutputs = 32 };
 struct PlannerArgs {
-  int B, n_steps, N_gait, k_mpc, mode, k, k_footsteps, refresh, code_scalar;
+  int B, n_steps, N_gait, k_mpc, mode, k, k_footsteps, refresh, code_scalar, q_ld;
   double dt_mpc, dt_wbc, T_gait, T_mpc, h_ref, k_feedback, g, L, max_height, lock_time, z_average;
   double shoulders[12], init_target[12], init_pos[12];
   const double *q7, *hv, *vref, *target_in;
   const int32_t* code;
   double* ps;  // [items][B]
-  double *xref, *fsteps, *gait, *target, *feet_pva;
+  double *xref, *fsteps, *gait, *target, *feet_pva, *contacts;
 };
 int planner_state_items(int N_gait);
 

@@ -56,7 +56,8 @@ SIGNATURES = {
     "qrw_fixed_feet_host": (C.c_int, [_vp] + [_dp] * 7),
     "qrw_get_base_inertia_diag": (C.c_int, [_vp, _dp]),
     "qrw_planner_init": (C.c_int, [_vp, _vp, _vp]),
-    "qrw_planner_step": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qrw_planner_step": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp]),
     "qrw_planner_call_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_int32, _dp,
                                         C.c_double, _dp, _dp, _dp, _dp, _dp]),
     "qrw_planner_get_host": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -298,7 +299,8 @@ class Batch:
         self.k_mpc = int(k_mpc)
 
     def planner_step(self, k, q7, hv, vref, code=0, out=None):
-        """Device API: q7 (B,7), hv (B,6), vref (B,6) CUDA float64; code int or CUDA int32 (B,). Returns dict."""
+        """Device API: q7 (B,7) or the full q (B,19) of controller_update_state, hv (B,6), vref (B,6) CUDA float64; code int
+        or CUDA int32 (B,). Returns dict (xref, fsteps, gait, target, feet_pva, contacts)."""
         import torch
 
         B, N, Ng = self.B, self.N, self.N_gait
@@ -308,17 +310,21 @@ class Batch:
                        fsteps=torch.empty((B, Ng, 12), dtype=torch.float64, device=dev),
                        gait=torch.empty((B, Ng, 4), dtype=torch.float64, device=dev),
                        target=torch.empty((B, 3, 4), dtype=torch.float64, device=dev),
-                       feet_pva=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev))
+                       feet_pva=torch.empty((B, 3, 3, 4), dtype=torch.float64, device=dev),
+                       contacts=torch.empty((B, 4), dtype=torch.float64, device=dev))
         cptr, cs = _vp(0), 0
         if isinstance(code, torch.Tensor):
             cptr = _vp(code.data_ptr())
         else:
             cs = int(code)
-        _check(self._lib.qrw_planner_step(self._handle, int(k), self._dev(q7, (B, 7)), self._dev(hv, (B, 6)),
+        q_ld = int(q7.shape[-1]) if q7.dim() == 2 else 7
+        if q_ld not in (7, 19):
+            raise QrwError("q7 must have shape (B,7) or (B,19)")
+        _check(self._lib.qrw_planner_step(self._handle, int(k), self._dev(q7, (B, q_ld)), q_ld, self._dev(hv, (B, 6)),
                                           self._dev(vref, (B, 6)), cptr, cs, self._dev(out["xref"], (B, 12, N + 1)),
                                           self._dev(out["fsteps"], (B, Ng, 12)), self._dev(out["gait"], (B, Ng, 4)),
                                           self._dev(out["target"], (B, 3, 4)), self._dev(out["feet_pva"], (B, 3, 3, 4)),
-                                          self._stream()), "qrw_planner_step")
+                                          self._dev(out["contacts"], (B, 4)), self._stream()), "qrw_planner_step")
         return out
 
     def planner_call_host(self, mode, k=0, k_footsteps=0, refresh=False, q7=None, v6=None, vref6=None, code=0,

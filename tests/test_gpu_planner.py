@@ -138,7 +138,8 @@ def test_device_resident_control_step_matches_oracle(oracle_mod):
         plan = eng.planner_step(k, t(q7), t(hv), t(vref), 0)
         if k % k_mpc == 0:
             mpc_out = eng.mpc_solve(plan["xref"], plan["fsteps"], k)
-        contacts = plan["gait"][:, 0, :].contiguous()
+        contacts = plan["contacts"]
+        assert torch.equal(contacts, plan["gait"][:, 0, :])
         f_cmd = mpc_out[:, 12:, 0].contiguous()
         # feet goals: foot trajectory outputs expressed relative to the base height (scripts/Controller.py:294-296, yaw = 0)
         pg = plan["feet_pva"][:, 0].clone()
