@@ -140,6 +140,231 @@ __device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int 
 
 }  // namespace
 
+// Force block of the KKT system of one horizon step, per quad: F_k (12x12, rows 3j..3j+2 in lane j) is built and
+// inverted in place by Gauss-Jordan with quad DPP broadcasts, then Phi = F^-1 Gbar' (rows of lane j) and
+// W = Gbar Phi (6x6, summed over the quad).  omL / omA: omega_D of the linear / angular velocity rows of the step
+// (the values lanes 2 / 3 of the quad own), omS / omC: of this lane's force-enable / cone rows.
+__device__ __forceinline__ void force_block_factor(bool act, int j, const double (&Bang)[3][3], const double (&sfl)[3],
+                                                   const double (&iDf)[3], const double (&omL)[3], const double (&omA)[3],
+                                                   const double (&omS)[3], const double (&omC)[5], double cs, double wF,
+                                                   double sigma, double dtm, double mu, double (&Fi)[3][12],
+                                                   double (&Ph)[3][6], double (&W)[6][6]) {
+  // ---- force block F_k (rows of foot j), inverted inside the quad by Gauss-Jordan
+  double Ball[3][12];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      Ball[r][0 + t] = quad_bcast<0>(Bang[r][t]);
+      Ball[r][3 + t] = quad_bcast<1>(Bang[r][t]);
+      Ball[r][6 + t] = quad_bcast<2>(Bang[r][t]);
+      Ball[r][9 + t] = quad_bcast<3>(Bang[r][t]);
+    }
+  const double s4 = omC[0] + omC[1] + omC[2] + omC[3];
+  double cone[3][3] = {{omC[0] + omC[1], 0.0, -mu * (omC[0] - omC[1])},
+                       {0.0, omC[2] + omC[3], -mu * (omC[2] - omC[3])},
+                       {-mu * (omC[0] - omC[1]), -mu * (omC[2] - omC[3]), mu * mu * s4 + omC[4]}};
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int cb = 0; cb < 12; cb++) {
+      const int jb = cb / 3, tb = cb % 3;
+      double v = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) v += omA[r] * Bang[r][t] * Ball[r][cb];
+      if (tb == t) v += dtm * dtm * omL[t];
+      if (jb == j) {
+        v += cone[t][tb];
+        if (tb == t) v += cs * wF + sigma * iDf[t] * iDf[t] + sfl[t] * sfl[t] * omS[t];
+      }
+      Fi[t][cb] = act ? v : ((jb == j && tb == t) ? 1.0 : 0.0);
+    }
+#pragma unroll
+  for (int p = 0; p < 12; p++) {
+    const int jp = p / 3, tp = p % 3;
+    double prow[12];
+#pragma unroll
+    for (int cb = 0; cb < 12; cb++) {
+      const double src = Fi[tp][cb];
+      prow[cb] = (jp == 0) ? quad_bcast<0>(src) : (jp == 1) ? quad_bcast<1>(src) : (jp == 2) ? quad_bcast<2>(src) : quad_bcast<3>(src);
+    }
+    const double d = 1.0 / prow[p];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const bool isp = (j == jp) && (t == tp);
+      const double fcol = Fi[t][p];
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) {
+        double v;
+        if (cb == p) v = isp ? d : -fcol * d;
+        else v = isp ? prow[cb] * d : Fi[t][cb] - fcol * prow[cb] * d;
+        Fi[t][cb] = v;
+      }
+    }
+  }
+  // Phi = F^-1 Gbar' (12x6), Gbar = -diag(omega_D[6:12]) B[6:12,:]
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) Ph[t][c] = -omL[c] * dtm * (Fi[t][c] + Fi[t][3 + c] + Fi[t][6 + c] + Fi[t][9 + c]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double v = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) v += Fi[t][cb] * Ball[r][cb];
+      Ph[t][3 + r] = -omA[r] * v;
+    }
+  }
+  // W = Gbar Phi (6x6, symmetric), reduced over the quad
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int c2 = c; c2 < 6; c2++) {
+      double v = 0.0;
+      if (c < 3) v = -omL[c] * dtm * Ph[c][c2];
+      else {
+#pragma unroll
+        for (int t = 0; t < 3; t++) v += -omA[c - 3] * Bang[c - 3][t] * Ph[t][c2];
+      }
+      v = quad_sum(act ? v : 0.0);
+      W[c][c2] = v;
+      W[c2][c] = v;
+    }
+}
+
+// Twisted block LDL' over the states (see chain_sweep.h): chain A (steps 0..m-1 upwards), chain B (steps N-1..m+1
+// downwards), then the root step m; sequential in the step, the NT threads of the workgroup cooperate per step
+// (tid = 0..NT-1).  Reads sW, sOm, sDg, writes the chain matrices into sN; Di (may be null) receives rows
+// 3j..3j+2 of Delta_k^-1 of the calling lane's step k.
+template <int NT, typename LdsT>
+__device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int tid, int k, int j, double (*Di)[12]) {
+  constexpr int T = NT;
+  constexpr int NP = (kMatSz + NT - 1) / NT;
+  double* Mprev = L.sA;
+  double* Mcur = L.sB;
+  const int mroot = N >> 1;
+  for (int sidx = 0; sidx < N; sidx++) {
+    // visiting order: 0..m-1, N-1..m+1, m
+    const int kk = (sidx < mroot) ? sidx : (sidx < N - 1) ? (N - 1) - (sidx - mroot) : mroot;
+    const bool isroot = (sidx == N - 1);
+    const bool fromA = isroot ? (mroot > 0) : (kk < mroot && kk > 0);          // couples to an eliminated step kk-1
+    const bool fromB = isroot ? (mroot < N - 1) : (kk > mroot && kk < N - 1);  // couples to an eliminated step kk+1
+    const bool last = (kk + 1 == N);
+    const double* Wk = &L.sW[kk * kWSz];
+    const double* Wn = &L.sW[(last ? kk : kk + 1) * kWSz];
+    const double* om = &L.sOm[kk * 12];
+    const double* omn = &L.sOm[(last ? kk : kk + 1) * 12];
+    if (fromB) {  // Nt_kk = C_{kk+1}' Delta_{kk+1}^-1 (Mprev), stored negated, column-major, slot m + N-2-kk
+#pragma unroll
+      for (int s = 0; s < NP; s++) {
+        const int e = tid + T * s;
+        if (e < kMatSz) {
+          const int i = e / 12, ip = e % 12;
+          double v = -omn[i] * Mprev[i * 12 + ip];
+          if (i >= 6) {
+            v -= dt * omn[i - 6] * Mprev[(i - 6) * 12 + ip];
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) v += Wn[mm * 6 + (i - 6)] * Mprev[(6 + mm) * 12 + ip];
+          }
+          L.sN[(mroot + N - 2 - kk) * kSlot + ip * kCol + i] = -v;
+        }
+      }
+      wg_sync();
+    }
+#pragma unroll
+    for (int s = 0; s < NP; s++) {  // Delta_kk = Ttilde_kk - N_kk C_kk' - Nt_kk C_{kk+1}
+      const int e = tid + T * s;
+      if (e < kMatSz) {
+        const int i = e / 12, ip = e % 12;
+        double v = 0.0;
+        if (i == ip) {
+          v = L.sDg[kk * 12 + i] + om[i];
+          if (!last) {
+            v += omn[i];
+            if (i >= 6) v += dt * dt * omn[i - 6];
+          }
+        } else if (!last && (ip == i + 6)) {
+          v = dt * omn[i];
+        } else if (!last && (i == ip + 6)) {
+          v = dt * omn[ip];
+        }
+        if (i >= 6 && ip >= 6) {
+          v -= Wk[(i - 6) * 6 + (ip - 6)];
+          if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
+        }
+        if (fromA) {  // + (-N_kk)[i][m] * C_kk[ip][m]
+          const double* nN = &L.sN[(kk - 1) * kSlot];
+          double acc = -om[ip] * nN[ip * kCol + i];
+          if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * kCol + i];
+          else {
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * kCol + i];
+          }
+          v += acc;
+        }
+        if (fromB) {  // + (-Nt_kk)[i][m] * C_{kk+1}[m][ip]
+          const double* nN = &L.sN[(mroot + N - 2 - kk) * kSlot];
+          double acc = -omn[ip] * nN[ip * kCol + i];
+          if (ip >= 6) {
+            acc -= dt * omn[ip - 6] * nN[(ip - 6) * kCol + i];
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * kCol + i];
+          }
+          v += acc;
+        }
+        Mcur[e] = v;
+      }
+    }
+    wg_sync();
+    for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_kk
+      double nv[3];
+      const double d = 1.0 / Mcur[p * 12 + p];
+#pragma unroll
+      for (int s = 0; s < NP; s++) {
+        const int e = tid + T * s;
+        nv[s] = 0.0;
+        if (e < kMatSz) {
+          const int i = e / 12, ip = e % 12;
+          const double aip = Mcur[i * 12 + p], apj = Mcur[p * 12 + ip], aij = Mcur[e];
+          if (i == p) nv[s] = (ip == p) ? d : apj * d;
+          else nv[s] = (ip == p) ? -aip * d : aij - aip * apj * d;
+        }
+      }
+      wg_sync();
+#pragma unroll
+      for (int s = 0; s < NP; s++) {
+        const int e = tid + T * s;
+        if (e < kMatSz) Mcur[e] = nv[s];
+      }
+      wg_sync();
+    }
+    if (Di != nullptr && k == kk) {
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int c = 0; c < 12; c++) Di[t][c] = Mcur[(3 * j + t) * 12 + c];
+    }
+    if (!isroot && kk < mroot) {  // N_{kk+1} = C_{kk+1} Delta_kk^-1, stored negated, column-major, slot kk
+#pragma unroll
+      for (int s = 0; s < NP; s++) {
+        const int e = tid + T * s;
+        if (e < kMatSz) {
+          const int i = e / 12, ip = e % 12;
+          double v = -omn[i] * Mcur[i * 12 + ip];
+          if (i < 6) v -= dt * omn[i] * Mcur[(i + 6) * 12 + ip];
+          else {
+#pragma unroll
+            for (int mm = 0; mm < 6; mm++) v += Wn[(i - 6) * 6 + mm] * Mcur[(6 + mm) * 12 + ip];
+          }
+          L.sN[kk * kSlot + ip * kCol + i] = -v;
+        }
+      }
+    }
+    double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
+    wg_sync();
+  }
+}
+
 // FULL: N == 16 * NW, every lane owns a live horizon step (the masks on `act` fold away)
 template <int NW, bool FULL>
 __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
@@ -453,91 +678,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) { omD[t] = rho_eq * Ed[t] * Ed[t]; omS[t] = rho_eq * Es[t] * Es[t]; }
 #pragma unroll
       for (int c = 0; c < 5; c++) omC[c] = rho * Ec[c] * Ec[c];
-      // ---- force block F_k (rows of foot j), inverted inside the quad by Gauss-Jordan
-      double Ball[3][12];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-          Ball[r][0 + t] = quad_bcast<0>(Bang[r][t]);
-          Ball[r][3 + t] = quad_bcast<1>(Bang[r][t]);
-          Ball[r][6 + t] = quad_bcast<2>(Bang[r][t]);
-          Ball[r][9 + t] = quad_bcast<3>(Bang[r][t]);
-        }
-      double omL[3], omA[3];
+      double omL[3], omA[3], W[6][6];
 #pragma unroll
       for (int t = 0; t < 3; t++) { omL[t] = quad_bcast<2>(omD[t]); omA[t] = quad_bcast<3>(omD[t]); }
-      const double s4 = omC[0] + omC[1] + omC[2] + omC[3];
-      double cone[3][3] = {{omC[0] + omC[1], 0.0, -mu * (omC[0] - omC[1])},
-                           {0.0, omC[2] + omC[3], -mu * (omC[2] - omC[3])},
-                           {-mu * (omC[0] - omC[1]), -mu * (omC[2] - omC[3]), mu * mu * s4 + omC[4]}};
-#pragma unroll
-      for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int cb = 0; cb < 12; cb++) {
-          const int jb = cb / 3, tb = cb % 3;
-          double v = 0.0;
-#pragma unroll
-          for (int r = 0; r < 3; r++) v += omA[r] * Bang[r][t] * Ball[r][cb];
-          if (tb == t) v += dtm * dtm * omL[t];
-          if (jb == j) {
-            v += cone[t][tb];
-            if (tb == t) v += cs * wF + sigma * iDf[t] * iDf[t] + sfl[t] * sfl[t] * omS[t];
-          }
-          Fi[t][cb] = act ? v : ((jb == j && tb == t) ? 1.0 : 0.0);
-        }
-#pragma unroll
-      for (int p = 0; p < 12; p++) {
-        const int jp = p / 3, tp = p % 3;
-        double prow[12];
-#pragma unroll
-        for (int cb = 0; cb < 12; cb++) {
-          const double src = Fi[tp][cb];
-          prow[cb] = (jp == 0) ? quad_bcast<0>(src) : (jp == 1) ? quad_bcast<1>(src) : (jp == 2) ? quad_bcast<2>(src) : quad_bcast<3>(src);
-        }
-        const double d = 1.0 / prow[p];
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const bool isp = (j == jp) && (t == tp);
-          const double fcol = Fi[t][p];
-#pragma unroll
-          for (int cb = 0; cb < 12; cb++) {
-            double v;
-            if (cb == p) v = isp ? d : -fcol * d;
-            else v = isp ? prow[cb] * d : Fi[t][cb] - fcol * prow[cb] * d;
-            Fi[t][cb] = v;
-          }
-        }
-      }
-      // Phi = F^-1 Gbar' (12x6), Gbar = -diag(omega_D[6:12]) B[6:12,:]
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) Ph[t][c] = -omL[c] * dtm * (Fi[t][c] + Fi[t][3 + c] + Fi[t][6 + c] + Fi[t][9 + c]);
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          double v = 0.0;
-#pragma unroll
-          for (int cb = 0; cb < 12; cb++) v += Fi[t][cb] * Ball[r][cb];
-          Ph[t][3 + r] = -omA[r] * v;
-        }
-      }
-      // W = Gbar Phi (6x6, symmetric), reduced over the quad
-      double W[6][6];
-#pragma unroll
-      for (int c = 0; c < 6; c++)
-#pragma unroll
-        for (int c2 = c; c2 < 6; c2++) {
-          double v = 0.0;
-          if (c < 3) v = -omL[c] * dtm * Ph[c][c2];
-          else {
-#pragma unroll
-            for (int t = 0; t < 3; t++) v += -omA[c - 3] * Bang[c - 3][t] * Ph[t][c2];
-          }
-          v = quad_sum(act ? v : 0.0);
-          W[c][c2] = v;
-          W[c2][c] = v;
-        }
+      force_block_factor(act, j, Bang, sfl, iDf, omL, omA, omS, omC, cs, wF, sigma, dtm, mu, Fi, Ph, W);
       wg_sync();
       if (act) {
         if (j == 0) {
@@ -553,131 +697,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         }
       }
       wg_sync();
-      // ---- twisted block LDL' over the states: chain A (steps 0..m-1 upwards), chain B (steps N-1..m+1 downwards),
-      // then the root step m; sequential in the step, whole workgroup per step
-      double* Mprev = L.sA;
-      double* Mcur = L.sB;
-      const int mroot = N >> 1;
-      for (int sidx = 0; sidx < N; sidx++) {
-        // visiting order: 0..m-1, N-1..m+1, m
-        const int kk = (sidx < mroot) ? sidx : (sidx < N - 1) ? (N - 1) - (sidx - mroot) : mroot;
-        const bool isroot = (sidx == N - 1);
-        const bool fromA = isroot ? (mroot > 0) : (kk < mroot && kk > 0);          // couples to an eliminated step kk-1
-        const bool fromB = isroot ? (mroot < N - 1) : (kk > mroot && kk < N - 1);  // couples to an eliminated step kk+1
-        const bool last = (kk + 1 == N);
-        const double* Wk = &L.sW[kk * kWSz];
-        const double* Wn = &L.sW[(last ? kk : kk + 1) * kWSz];
-        const double* om = &L.sOm[kk * 12];
-        const double* omn = &L.sOm[(last ? kk : kk + 1) * 12];
-        if (fromB) {  // Nt_kk = C_{kk+1}' Delta_{kk+1}^-1 (Mprev), stored negated, column-major, slot m + N-2-kk
-#pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const int e = tid + T * s;
-            if (e < kMatSz) {
-              const int i = e / 12, ip = e % 12;
-              double v = -omn[i] * Mprev[i * 12 + ip];
-              if (i >= 6) {
-                v -= dt * omn[i - 6] * Mprev[(i - 6) * 12 + ip];
-#pragma unroll
-                for (int mm = 0; mm < 6; mm++) v += Wn[mm * 6 + (i - 6)] * Mprev[(6 + mm) * 12 + ip];
-              }
-              L.sN[(mroot + N - 2 - kk) * kSlot + ip * kCol + i] = -v;
-            }
-          }
-          wg_sync();
-        }
-#pragma unroll
-        for (int s = 0; s < 3; s++) {  // Delta_kk = Ttilde_kk - N_kk C_kk' - Nt_kk C_{kk+1}
-          const int e = tid + T * s;
-          if (e < kMatSz) {
-            const int i = e / 12, ip = e % 12;
-            double v = 0.0;
-            if (i == ip) {
-              v = L.sDg[kk * 12 + i] + om[i];
-              if (!last) {
-                v += omn[i];
-                if (i >= 6) v += dt * dt * omn[i - 6];
-              }
-            } else if (!last && (ip == i + 6)) {
-              v = dt * omn[i];
-            } else if (!last && (i == ip + 6)) {
-              v = dt * omn[ip];
-            }
-            if (i >= 6 && ip >= 6) {
-              v -= Wk[(i - 6) * 6 + (ip - 6)];
-              if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
-            }
-            if (fromA) {  // + (-N_kk)[i][m] * C_kk[ip][m]
-              const double* nN = &L.sN[(kk - 1) * kSlot];
-              double acc = -om[ip] * nN[ip * kCol + i];
-              if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * kCol + i];
-              else {
-#pragma unroll
-                for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * kCol + i];
-              }
-              v += acc;
-            }
-            if (fromB) {  // + (-Nt_kk)[i][m] * C_{kk+1}[m][ip]
-              const double* nN = &L.sN[(mroot + N - 2 - kk) * kSlot];
-              double acc = -omn[ip] * nN[ip * kCol + i];
-              if (ip >= 6) {
-                acc -= dt * omn[ip - 6] * nN[(ip - 6) * kCol + i];
-#pragma unroll
-                for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * kCol + i];
-              }
-              v += acc;
-            }
-            Mcur[e] = v;
-          }
-        }
-        wg_sync();
-        for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_kk
-          double nv[3];
-          const double d = 1.0 / Mcur[p * 12 + p];
-#pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const int e = tid + T * s;
-            nv[s] = 0.0;
-            if (e < kMatSz) {
-              const int i = e / 12, ip = e % 12;
-              const double aip = Mcur[i * 12 + p], apj = Mcur[p * 12 + ip], aij = Mcur[e];
-              if (i == p) nv[s] = (ip == p) ? d : apj * d;
-              else nv[s] = (ip == p) ? -aip * d : aij - aip * apj * d;
-            }
-          }
-          wg_sync();
-#pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const int e = tid + T * s;
-            if (e < kMatSz) Mcur[e] = nv[s];
-          }
-          wg_sync();
-        }
-        if (k == kk) {
-#pragma unroll
-          for (int t = 0; t < 3; t++)
-#pragma unroll
-            for (int c = 0; c < 12; c++) Di[t][c] = Mcur[(3 * j + t) * 12 + c];
-        }
-        if (!isroot && kk < mroot) {  // N_{kk+1} = C_{kk+1} Delta_kk^-1, stored negated, column-major, slot kk
-#pragma unroll
-          for (int s = 0; s < 3; s++) {
-            const int e = tid + T * s;
-            if (e < kMatSz) {
-              const int i = e / 12, ip = e % 12;
-              double v = -omn[i] * Mcur[i * 12 + ip];
-              if (i < 6) v -= dt * omn[i] * Mcur[(i + 6) * 12 + ip];
-              else {
-#pragma unroll
-                for (int mm = 0; mm < 6; mm++) v += Wn[(i - 6) * 6 + mm] * Mcur[(6 + mm) * 12 + ip];
-              }
-              L.sN[kk * kSlot + ip * kCol + i] = -v;
-            }
-          }
-        }
-        double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
-        wg_sync();
-      }
+      chain_factorize<T>(L, N, dt, tid, k, j, Di);
     PH(0);
     }  // need_factor
 
