@@ -1,0 +1,73 @@
+"""API misuse and edge sizes through the C ABI on the GPU: errors are reported (never a crash, never a silent fallback),
+the smallest and the largest supported shapes work."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_invalid_configurations_are_refused():
+    import qrw_hip
+
+    for kw in (dict(batch=0), dict(batch=-3), dict(batch=2, n_steps=0), dict(batch=2, n_steps=33),
+               dict(batch=2, n_steps=16, N_gait=12), dict(batch=2, device=99)):
+        args = dict(batch=2, n_steps=16, N_gait=20)
+        args.update(kw)
+        with pytest.raises(qrw_hip.QrwError):
+            qrw_hip.Batch(args.pop("batch"), **args)
+    assert b"" != qrw_hip.load_library().qrw_last_error()
+
+
+def test_wrong_buffers_are_refused(synth_mod):
+    import torch
+    import qrw_hip
+
+    B, N = 3, 16
+    eng = qrw_hip.Batch(B, N)
+    d = synth_mod.SyntheticBatch(B, N).step(0)
+    with pytest.raises((qrw_hip.QrwError, ValueError)):
+        eng.mpc_solve_host(d["xref"][:2], d["fsteps"], 0)             # wrong batch dimension
+    x = torch.from_numpy(d["xref"]).cuda()
+    f = torch.from_numpy(d["fsteps"]).cuda()
+    with pytest.raises(qrw_hip.QrwError):
+        eng.mpc_solve(x.float(), f, 0)                                # wrong dtype
+    with pytest.raises(qrw_hip.QrwError):
+        eng.mpc_solve(x.transpose(1, 2), f, 0)                        # not contiguous / wrong shape
+    with pytest.raises(qrw_hip.QrwError):
+        eng.mpc_solve(x.cpu(), f, 0)                                  # host tensor on the device API
+    with pytest.raises(qrw_hip.QrwError):
+        eng.planner_step(0, torch.zeros((B, 7), dtype=torch.float64, device="cuda"),
+                         torch.zeros((B, 6), dtype=torch.float64, device="cuda"),
+                         torch.zeros((B, 6), dtype=torch.float64, device="cuda"))  # planner not initialised
+    out = eng.mpc_solve(x, f, 0)                                      # and the handle still works afterwards
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+
+
+def test_single_instance_and_odd_batch(oracle_mod, synth_mod):
+    import qrw_hip
+
+    for B in (1, 67):  # 67: not a multiple of the 16 instances a WBC wavefront holds nor of 64
+        sb = synth_mod.SyntheticBatch(B, 16, seed0=990000)
+        eng = qrw_hip.Batch(B, 16)
+        ref_m = [oracle_mod.MPC(0.02, 16, 0.32, 20) for _ in range(B)]
+        ref_w = [oracle_mod.WbcController(0.002) for _ in range(B)]
+        for s in range(3):
+            d = sb.step(s)
+            out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+            w = eng.wbc_compute_host(d["q"], d["dq"], np.ascontiguousarray(out[:, 12:, 0]), d["contacts"], d["pgoals"],
+                                     d["vgoals"], d["agoals"])
+            for b in sorted({0, B - 1}):
+                ref_m[b].run(s, d["xref"][b], d["fsteps"][b])
+                r = ref_m[b].get_latest_result()
+                assert np.allclose(out[b], r, rtol=1e-6, atol=1e-8)
+                ref_w[b].compute(d["q"][b], d["dq"][b], r[12:, 0], d["contacts"][b], d["pgoals"][b], d["vgoals"][b], d["agoals"][b])
+                assert np.allclose(w["tau_ff"][b], ref_w[b].tau_ff, rtol=1e-4, atol=1e-8)
+
+
+def test_gait_initialize_raises_like_the_reference():
+    import libquadruped_reactive_walking as lqrw
+
+    g = lqrw.Gait()
+    with pytest.raises(ValueError):  # src/Gait.cpp:30-31 throws std::invalid_argument
+        g.initialize(0.02, 0.32, 0.32, 10)
