@@ -299,7 +299,9 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
   int iter, status = kStatusUnsolved;
   double last_np = 0.0, last_nd = 0.0, pri_res = 0.0, dua_res = 0.0;
   const int max_iter = 4000;
-  for (iter = 1; iter <= max_iter; iter++) {
+  // padding quads (batch not a multiple of 16) skip the solve: their data is a copy of instance 0 with an identity
+  // KKT inverse, which never converges and would hold the whole wavefront for max_iter iterations
+  for (iter = 1; valid && iter <= max_iter; iter++) {
     if (need_factor) {  // Khat = c H + sigma D^-2 + rho G' E^2 G, inverted by Gauss-Jordan inside the quad
       need_factor = false;
       double om[5];
