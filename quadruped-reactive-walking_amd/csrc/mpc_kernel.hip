@@ -232,136 +232,179 @@ __device__ __forceinline__ void force_block_factor(bool act, int j, const double
     }
 }
 
-// Twisted block LDL' over the states (see chain_sweep.h): chain A (steps 0..m-1 upwards), chain B (steps N-1..m+1
-// downwards), then the root step m; sequential in the step, the NT threads of the workgroup cooperate per step
-// (tid = 0..NT-1).  Reads sW, sOm, sDg, writes the chain matrices into sN; Di (may be null) receives rows
-// 3j..3j+2 of Delta_k^-1 of the calling lane's step k.
+// ---- in-register Gauss-Jordan on the FP64 VALU: lane i of a 16-lane DPP row holds row i of a 12x12 matrix in m[0..11]
+// One pivot: every row gets  m[c] += m_P[c] * f  with m_P[c] read from lane P by row_newbcast (f = -m[P]/pivot for the
+// other rows, 1/pivot - 1 for row P itself), then column P is replaced.  12 pivots invert the matrix in place.
+#define QRW_GJ_FM(C) "v_fmac_f64_dpp %" #C ", %" #C ", %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+template <int P>
+__device__ __forceinline__ void gj_pivot(double (&m)[12], int i) {
+  double piv = 0.0;
+  const double one = 1.0;
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(piv) : "v"(m[P]), "v"(one), "n"(P));
+  const double d = 1.0 / piv;
+  const double f = (i == P) ? (d - 1.0) : (-m[P] * d);
+  asm("s_nop 1\n\t" QRW_GJ_FM(0) QRW_GJ_FM(1) QRW_GJ_FM(2) QRW_GJ_FM(3) QRW_GJ_FM(4) QRW_GJ_FM(5) QRW_GJ_FM(6) QRW_GJ_FM(7)
+      QRW_GJ_FM(8) QRW_GJ_FM(9) QRW_GJ_FM(10) QRW_GJ_FM(11)
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]),
+        "+v"(m[9]), "+v"(m[10]), "+v"(m[11])
+      : "v"(f), "n"(P));
+  m[P] = (i == P) ? d : f;
+}
+#undef QRW_GJ_FM
+__device__ __forceinline__ void gj_invert12(double (&m)[12], int i) {
+  gj_pivot<0>(m, i); gj_pivot<1>(m, i); gj_pivot<2>(m, i); gj_pivot<3>(m, i); gj_pivot<4>(m, i); gj_pivot<5>(m, i);
+  gj_pivot<6>(m, i); gj_pivot<7>(m, i); gj_pivot<8>(m, i); gj_pivot<9>(m, i); gj_pivot<10>(m, i); gj_pivot<11>(m, i);
+}
+// acc[c] += m_J[c] * coef for c = 0..11 (row J of the matrix held across the lanes, coef per lane)
+template <int J>
+__device__ __forceinline__ void row_bcast_fma(double (&acc)[12], const double (&m)[12], double coef) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %12, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %13, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %14, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %15, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %16, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %17, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %18, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %19, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %8, %20, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %9, %21, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %10, %22, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %11, %23, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+        "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
+      : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]),
+        "v"(m[10]), "v"(m[11]), "v"(coef), "n"(J));
+}
+// value of the same register six lanes below in the 16-lane row (0 where there is none)
+__device__ __forceinline__ double row_shr6(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x116, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x116, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Twisted block LDL' over the states (see chain_sweep.h), in registers: DPP row 0 of wavefront 0 factorises chain A
+// (steps 0..m-1 upwards), row 1 chain B (steps N-1..m+1 downwards) AT THE SAME TIME, lane i of a row holding row i of
+// the step's 12x12 block; both then assemble and invert the root step m.  Per step: build Delta = Ttilde - (coupling
+// to the step eliminated just before), invert it by in-register Gauss-Jordan, hand its rows to the quad that owns the
+// step (Di), and form the next coupling matrix (negated, into sN).  Replaces a version that kept the block in LDS and
+// needed two workgroup barriers per pivot (about 7x the time).
 template <int NT, typename LdsT>
 __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int tid, int k, int j, double (*Di)[12]) {
-  constexpr int T = NT;
-  constexpr int NP = (kMatSz + NT - 1) / NT;
-  double* Mprev = L.sA;
-  double* Mcur = L.sB;
-  const int mroot = N >> 1;
-  for (int sidx = 0; sidx < N; sidx++) {
-    // visiting order: 0..m-1, N-1..m+1, m
-    const int kk = (sidx < mroot) ? sidx : (sidx < N - 1) ? (N - 1) - (sidx - mroot) : mroot;
-    const bool isroot = (sidx == N - 1);
-    const bool fromA = isroot ? (mroot > 0) : (kk < mroot && kk > 0);          // couples to an eliminated step kk-1
-    const bool fromB = isroot ? (mroot < N - 1) : (kk > mroot && kk < N - 1);  // couples to an eliminated step kk+1
+  const int mroot = N >> 1, nA = mroot, nB = N - 1 - mroot;
+  const int steps = (nA > nB) ? nA : nB;
+  const int lane = tid & 63;
+  const bool worker = tid < 64;
+  const bool rowB = (lane & 16) != 0;
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const int i6 = (i >= 6) ? i - 6 : i;  // index into the 6x6 velocity block (clamped for the position rows)
+  const double sA = rowB ? 0.0 : 1.0, sB = rowB ? 1.0 : 0.0;
+  const double hi6 = (i >= 6) ? 1.0 : 0.0, lo6 = (i < 6) ? 1.0 : 0.0;
+  double nn[12];  // row i of the negated coupling matrix made by this chain's previous step
+#pragma unroll
+  for (int c = 0; c < 12; c++) nn[c] = 0.0;
+  for (int s = 0; s <= steps; s++) {
+    const bool root = (s == steps);
+    const bool active = root ? true : (rowB ? (s < nB) : (s < nA));
+    const bool hasprev = root ? (rowB ? (nB > 0) : (nA > 0)) : (s > 0);
+    int kk = root ? mroot : (rowB ? N - 1 - s : s);
+    if (!active) kk = mroot;
     const bool last = (kk + 1 == N);
-    const double* Wk = &L.sW[kk * kWSz];
-    const double* Wn = &L.sW[(last ? kk : kk + 1) * kWSz];
-    const double* om = &L.sOm[kk * 12];
-    const double* omn = &L.sOm[(last ? kk : kk + 1) * 12];
-    if (fromB) {  // Nt_kk = C_{kk+1}' Delta_{kk+1}^-1 (Mprev), stored negated, column-major, slot m + N-2-kk
+    const int kn = last ? kk : kk + 1;
+    const double nl = last ? 0.0 : 1.0;
+    double* Mout = rowB ? L.sB : L.sA;
+    double m[12];
+    if (worker) {
+      // ---- Ttilde_kk, row i
+      const double omki = L.sOm[kk * 12 + i], omni = nl * L.sOm[kn * 12 + i], omn6 = nl * L.sOm[kn * 12 + i6];
+      const double diag = (L.sDg[kk * 12 + i] + omki) + (omni + hi6 * (dt * dt * omn6));
 #pragma unroll
-      for (int s = 0; s < NP; s++) {
-        const int e = tid + T * s;
-        if (e < kMatSz) {
-          const int i = e / 12, ip = e % 12;
-          double v = -omn[i] * Mprev[i * 12 + ip];
-          if (i >= 6) {
-            v -= dt * omn[i - 6] * Mprev[(i - 6) * 12 + ip];
+      for (int c = 0; c < 12; c++) {
+        double v = (c == i) ? diag : 0.0;
+        if (c >= 6) v = (c - 6 == i) ? dt * omni : v;          // (i, i+6), i < 6
+        if (c < 6) v = (c + 6 == i) ? dt * omn6 : v;           // (i, i-6), i >= 6
+        if (c >= 6) v -= hi6 * (L.sW[kk * kWSz + i6 * 6 + (c - 6)] + nl * L.sW[kn * kWSz + i6 * 6 + (c - 6)]);
+        m[c] = v;
+      }
+      // ---- Schur term of the step this chain eliminated just before: chain A  -N_kk C_kk', chain B  -Nt_kk C_{kk+1}
+      {
+        const int ks = rowB ? kn : kk;
+        const double* omS = &L.sOm[ks * 12];
+        const double* WS = &L.sW[ks * kWSz];
+        double term[12];
 #pragma unroll
-            for (int mm = 0; mm < 6; mm++) v += Wn[mm * 6 + (i - 6)] * Mprev[(6 + mm) * 12 + ip];
+        for (int c = 0; c < 6; c++) term[c] = -omS[c] * nn[c] - sA * (dt * omS[c]) * nn[c + 6];
+#pragma unroll
+        for (int c = 6; c < 12; c++) {
+          double v = -omS[c] * nn[c] - sB * (dt * omS[c - 6]) * nn[c - 6];
+#pragma unroll
+          for (int mm = 0; mm < 6; mm++) v += WS[(c - 6) * 6 + mm] * nn[6 + mm];
+          term[c] = v;
+        }
+        if (root) {  // the root couples to both chains: add the other chain's term
+#pragma unroll
+          for (int c = 0; c < 12; c++) {
+            const double mine = hasprev ? term[c] : 0.0;
+            const double other = shfl(mine, lane ^ 16);
+            m[c] += mine + other;
           }
-          L.sN[(mroot + N - 2 - kk) * kSlot + ip * kCol + i] = -v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 12; c++) m[c] += hasprev ? term[c] : 0.0;
         }
       }
-      wg_sync();
-    }
+      gj_invert12(m, i);
+      if (active && lane < 32 && (lane & 15) < 12 && !(root && rowB)) {
 #pragma unroll
-    for (int s = 0; s < NP; s++) {  // Delta_kk = Ttilde_kk - N_kk C_kk' - Nt_kk C_{kk+1}
-      const int e = tid + T * s;
-      if (e < kMatSz) {
-        const int i = e / 12, ip = e % 12;
-        double v = 0.0;
-        if (i == ip) {
-          v = L.sDg[kk * 12 + i] + om[i];
-          if (!last) {
-            v += omn[i];
-            if (i >= 6) v += dt * dt * omn[i - 6];
-          }
-        } else if (!last && (ip == i + 6)) {
-          v = dt * omn[i];
-        } else if (!last && (i == ip + 6)) {
-          v = dt * omn[ip];
-        }
-        if (i >= 6 && ip >= 6) {
-          v -= Wk[(i - 6) * 6 + (ip - 6)];
-          if (!last) v -= Wn[(i - 6) * 6 + (ip - 6)];
-        }
-        if (fromA) {  // + (-N_kk)[i][m] * C_kk[ip][m]
-          const double* nN = &L.sN[(kk - 1) * kSlot];
-          double acc = -om[ip] * nN[ip * kCol + i];
-          if (ip < 6) acc -= dt * om[ip] * nN[(ip + 6) * kCol + i];
-          else {
-#pragma unroll
-            for (int mm = 0; mm < 6; mm++) acc += Wk[(ip - 6) * 6 + mm] * nN[(6 + mm) * kCol + i];
-          }
-          v += acc;
-        }
-        if (fromB) {  // + (-Nt_kk)[i][m] * C_{kk+1}[m][ip]
-          const double* nN = &L.sN[(mroot + N - 2 - kk) * kSlot];
-          double acc = -omn[ip] * nN[ip * kCol + i];
-          if (ip >= 6) {
-            acc -= dt * omn[ip - 6] * nN[(ip - 6) * kCol + i];
-#pragma unroll
-            for (int mm = 0; mm < 6; mm++) acc += Wn[mm * 6 + (ip - 6)] * nN[(6 + mm) * kCol + i];
-          }
-          v += acc;
-        }
-        Mcur[e] = v;
+        for (int c = 0; c < 12; c++) Mout[i * 12 + c] = m[c];
       }
     }
-    wg_sync();
-    for (int p = 0; p < 12; p++) {  // in-place Gauss-Jordan inverse of Delta_kk
-      double nv[3];
-      const double d = 1.0 / Mcur[p * 12 + p];
+    __syncthreads();
+    if (Di != nullptr) {
+      const int kA = root ? mroot : ((s < nA) ? s : -1), kB = root ? -1 : ((s < nB) ? N - 1 - s : -1);
+      if (k == kA || k == kB) {
+        const double* Mi = (k == kB) ? L.sB : L.sA;
 #pragma unroll
-      for (int s = 0; s < NP; s++) {
-        const int e = tid + T * s;
-        nv[s] = 0.0;
-        if (e < kMatSz) {
-          const int i = e / 12, ip = e % 12;
-          const double aip = Mcur[i * 12 + p], apj = Mcur[p * 12 + ip], aij = Mcur[e];
-          if (i == p) nv[s] = (ip == p) ? d : apj * d;
-          else nv[s] = (ip == p) ? -aip * d : aij - aip * apj * d;
-        }
-      }
-      wg_sync();
+        for (int t = 0; t < 3; t++)
 #pragma unroll
-      for (int s = 0; s < NP; s++) {
-        const int e = tid + T * s;
-        if (e < kMatSz) Mcur[e] = nv[s];
-      }
-      wg_sync();
-    }
-    if (Di != nullptr && k == kk) {
-#pragma unroll
-      for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int c = 0; c < 12; c++) Di[t][c] = Mcur[(3 * j + t) * 12 + c];
-    }
-    if (!isroot && kk < mroot) {  // N_{kk+1} = C_{kk+1} Delta_kk^-1, stored negated, column-major, slot kk
-#pragma unroll
-      for (int s = 0; s < NP; s++) {
-        const int e = tid + T * s;
-        if (e < kMatSz) {
-          const int i = e / 12, ip = e % 12;
-          double v = -omn[i] * Mcur[i * 12 + ip];
-          if (i < 6) v -= dt * omn[i] * Mcur[(i + 6) * 12 + ip];
-          else {
-#pragma unroll
-            for (int mm = 0; mm < 6; mm++) v += Wn[(i - 6) * 6 + mm] * Mcur[(6 + mm) * 12 + ip];
-          }
-          L.sN[kk * kSlot + ip * kCol + i] = -v;
-        }
+          for (int c = 0; c < 12; c++) Di[t][c] = Mi[(3 * j + t) * 12 + c];
       }
     }
-    double* tmp = Mprev; Mprev = Mcur; Mcur = tmp;
-    wg_sync();
+    if (worker && !root) {
+      // ---- next coupling matrix, negated: chain A  -N_{kk+1} = -C_{kk+1} Delta_kk^-1 (slot kk),
+      //                                      chain B  -Nt_{kk-1} = -C_kk' Delta_kk^-1   (slot m + N-2-(kk-1))
+      const double omki = L.sOm[kk * 12 + i], omni = L.sOm[kn * 12 + i];
+      const double omk6 = L.sOm[kk * 12 + i6];
+      const double* Wc = rowB ? &L.sW[kk * kWSz] : &L.sW[kn * kWSz];
+      double nx[12], coef[6];
+      const double own = rowB ? omki : omni;
+#pragma unroll
+      for (int c = 0; c < 12; c++) nx[c] = own * m[c];
+      // rows 6..11 of Delta^-1: the 6x6 velocity-block coupling (both chains; W is symmetric) and chain A's dt term
+#pragma unroll
+      for (int mm = 0; mm < 6; mm++) {
+        double cf = -hi6 * Wc[i6 * 6 + mm];
+        if (mm == i) cf = sA * (dt * omni);  // i < 6 only: row i+6
+        coef[mm] = cf;
+      }
+      row_bcast_fma<6>(nx, m, coef[0]); row_bcast_fma<7>(nx, m, coef[1]); row_bcast_fma<8>(nx, m, coef[2]);
+      row_bcast_fma<9>(nx, m, coef[3]); row_bcast_fma<10>(nx, m, coef[4]); row_bcast_fma<11>(nx, m, coef[5]);
+      // chain B's dt term: row i-6 (i >= 6)
+      {
+        const double cb = sB * hi6 * (dt * omk6);
+#pragma unroll
+        for (int c = 0; c < 12; c++) nx[c] += cb * row_shr6(m[c]);
+      }
+      if (active && lane < 32 && (lane & 15) < 12) {
+        const int slot = rowB ? (mroot + N - 2 - (kk - 1)) : kk;
+#pragma unroll
+        for (int c = 0; c < 12; c++) L.sN[slot * kSlot + c * kCol + i] = nx[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 12; c++) nn[c] = active ? nx[c] : nn[c];
+    }
+    __syncthreads();
   }
 }
 
