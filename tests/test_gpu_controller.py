@@ -86,7 +86,7 @@ def test_closed_loop_matches_chained_oracles(oracle_mod, mode):
     import controller_oracle as co
     from Controller import Controller_batch
 
-    B, iters = 5, 45
+    B, iters = 5, (160 if mode == "sync" else 45)
     lag = {"sync": 0, "async_lag0": 0, "async_lag3": 3}[mode]
     rng = np.random.default_rng(3)
     ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag)
