@@ -203,6 +203,22 @@ int qrw_controller_result(qrw_handle h, const double *d_tau_ff, const double *d_
                           const double *d_q_filt, const double *d_v_secu, double *d_result, int32_t *d_error_flag,
                           void *stream);
 
+/* Fused forms of the above, one launch each, for the device-resident control loop (same arithmetic):
+ * qrw_control_pre = qrw_controller_update_state + qrw_planner_step (fed with its q, h_v, v_ref) and, when d_x_f_mpc is
+ * not NULL (the MPC result to use is already known: every iteration that does not solve), + qrw_controller_wbc_inputs;
+ * qrw_wbc_compute_result = qrw_wbc_compute + qrw_controller_result (scripts/Controller.py:200-326 end to end in two
+ * launches plus the MPC solve every k_mpc-th iteration).  Operands as in the separate entry points. */
+int qrw_control_pre(qrw_handle h, int32_t k, const double *d_joy_vref, const double *d_q_filt, const double *d_v_filt,
+                    const double *d_rpy, const int32_t *d_code, int32_t code_scalar, const double *d_x_f_mpc, double *d_q,
+                    double *d_v, double *d_hv, double *d_vref, double *d_oRh_oTh, double *d_xref, double *d_fsteps,
+                    double *d_gait, double *d_target, double *d_feet_pva, double *d_contacts, double *d_x_f_wbc,
+                    double *d_q_wbc, double *d_b_v, double *d_f_cmd, double *d_feet_cmd, void *stream);
+int qrw_wbc_compute_result(qrw_handle h, const double *d_q, const double *d_dq, const double *d_f_cmd,
+                           const double *d_contacts, const double *d_pgoals, const double *d_vgoals,
+                           const double *d_agoals, double *d_tau_ff, double *d_qdes, double *d_vdes,
+                           double *d_f_with_delta, double *d_ddq_res, double *d_feet, const double *d_q_filt,
+                           const double *d_v_secu, double *d_result, int32_t *d_error_flag, void *stream);
+
 /* ---------------- asynchronous MPC ----------------
  * The reference runs the MPC in a child process on its own CPU core and polls a shared flag
  * (scripts/MPC_Wrapper.py:150-298).  Here the MPC gets its own HIP stream restricted to a subset of the compute

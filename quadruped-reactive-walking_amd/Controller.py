@@ -21,7 +21,7 @@ class Result:
 
 class Controller_batch:
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
-                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None):
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
 
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
@@ -53,6 +53,8 @@ class Controller_batch:
         self._not_first_iter = False
         self._st = self._plan = self._wi = self._wbc = self._res = None
         self.x_f_mpc = self._mpc_default
+        self.fused = bool(fused)  # two launches per iteration (+ the solve) instead of five; same arithmetic
+        self._pre = self._post = None
         self.multiprocessing = bool(multiprocessing)
         self.mpc_lag = mpc_lag
         if self.multiprocessing:
@@ -119,21 +121,12 @@ class Controller_batch:
             self._adopt(ready, wait=self.mpc_lag is not None)
 
     def _compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code):
+        if self.fused:
+            return self._compute_fused(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
         b, k = self._b, self.k
         self._st = st = b.controller_update_state(joy_v_ref, q_filt, v_filt, rpy, out=self._st)
         self._plan = plan = b.planner_step(k, st["q"], st["h_v"], st["v_ref"], joystick_code, out=self._plan)
-        if (k % self.k_mpc) == 0:
-            if self.multiprocessing:
-                self._solve_async(plan, k)
-            else:
-                self._mpc_out = b.mpc_solve(plan["xref"], plan["fsteps"], k, out=self._mpc_out)
-        if self.multiprocessing:
-            self._poll(k)
-        if self._not_first_iter and self._mpc_out is not None:
-            self.x_f_mpc = self._mpc_out
-        else:
-            self._not_first_iter = True
-            self.x_f_mpc = self._mpc_default
+        self._mpc_step(plan, k)
         self._wi = wi = b.controller_wbc_inputs(self.x_f_mpc, plan["xref"], plan["feet_pva"], st["v"], out=self._wi)
         fc = wi["feet_cmd"]
         self._wbc = w = b.wbc_compute(wi["q_wbc"], wi["b_v"], wi["f_cmd"], plan["contacts"], fc[0], fc[1], fc[2],
@@ -141,6 +134,48 @@ class Controller_batch:
         self._res = b.controller_result(w["tau_ff"], w["qdes"], w["vdes"], q_filt, v_secu, out=self._res)
         self.result = Result(self._res["result"])
         self.error_flag = self._res["error_flag"]
+        self.k += 1
+        return self.result
+
+    def _mpc_step(self, plan, k):
+        """Solve every k_mpc-th iteration (synchronously or handed to the MPC stream) and pick the result to use."""
+        if (k % self.k_mpc) == 0:
+            if self.multiprocessing:
+                self._solve_async(plan, k)
+            else:
+                self._mpc_out = self._b.mpc_solve(plan["xref"], plan["fsteps"], k, out=self._mpc_out)
+        if self.multiprocessing:
+            self._poll(k)
+        if self._not_first_iter and self._mpc_out is not None:
+            self.x_f_mpc = self._mpc_out
+        else:
+            self._not_first_iter = True
+            self.x_f_mpc = self._mpc_default
+
+    def _compute_fused(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code):
+        b, k = self._b, self.k
+        if (k % self.k_mpc) == 0:
+            # this iteration hands new data to the MPC: which result the WBC uses is only known after that, so the
+            # WBC targets are assembled by the separate entry point (one extra launch every k_mpc-th iteration)
+            self._pre = p = b.control_pre(k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, x_f_mpc=None, out=self._pre)
+            self._mpc_step(p, k)
+            b.controller_wbc_inputs(self.x_f_mpc, p["xref"], p["feet_pva"], p["v"], out=p)
+        else:
+            if self.multiprocessing:
+                self._poll(k)
+            if self._not_first_iter and self._mpc_out is not None:
+                self.x_f_mpc = self._mpc_out
+            else:
+                self._not_first_iter = True
+                self.x_f_mpc = self._mpc_default
+            self._pre = p = b.control_pre(k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, x_f_mpc=self.x_f_mpc,
+                                          out=self._pre)
+        fc = p["feet_cmd"]
+        self._post = w = b.wbc_compute_result(p["q_wbc"], p["b_v"], p["f_cmd"], p["contacts"], fc[0], fc[1], fc[2], q_filt,
+                                              v_secu, out=self._post)
+        self._res = w
+        self.result = Result(w["result"])
+        self.error_flag = w["error_flag"]
         self.k += 1
         return self.result
 

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "controller_glue.h"
 #include "qrw_kernels.h"
 
 namespace qrw {
@@ -343,9 +344,7 @@ __device__ void traj_store(const FootTraj& f, const PS& s, const Lay& L) {
 }  // namespace
 
 // One thread per instance; see the note above on the register representation.
-__global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+__device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
   const Lay L = make_layout(a.N_gait);
   const int Ng = a.N_gait;
   PS s;
@@ -611,6 +610,23 @@ __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
 }
 #undef FSI
 
+__global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  planner_body(a, b);
+}
+
+// Fused head of a control iteration (scripts/Controller.py:218-296): Controller.updateState, the four planners and --
+// when the MPC result to use is already known (every iteration but the ones that solve) -- the WBC target assembly,
+// one thread per instance, one launch.  The pieces hand over through their HBM operands (same thread, program order).
+__global__ __launch_bounds__(64) void control_pre_kernel(ControllerArgs cu, PlannerArgs p, ControllerArgs cw, int with_wbc_inputs) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.B) return;
+  glue::update_state(cu, b);
+  planner_body(p, b);
+  if (with_wbc_inputs) glue::wbc_inputs(cw, b);
+}
+
 int planner_state_items(int N_gait) { return make_layout(N_gait).total; }
 
 int planner_item_offset(int N_gait, int which) {
@@ -636,6 +652,12 @@ int planner_item_offset(int N_gait, int which) {
     case 17: return L.fttgt;
     default: return -1;
   }
+}
+
+int control_pre_launch(const ControllerArgs& cu, const PlannerArgs& p, const ControllerArgs& cw, int with_wbc_inputs,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(control_pre_kernel, dim3((p.B + 63) / 64), dim3(64), 0, stream, cu, p, cw, with_wbc_inputs);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int planner_launch(const PlannerArgs& a, hipStream_t stream) {

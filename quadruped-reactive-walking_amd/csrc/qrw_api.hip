@@ -292,6 +292,27 @@ extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_
   return 0;
 }
 
+extern "C" int qrw_wbc_compute_result(qrw_handle h, const double* d_q, const double* d_dq, const double* d_f_cmd,
+                                      const double* d_contacts, const double* d_pgoals, const double* d_vgoals,
+                                      const double* d_agoals, double* d_tau_ff, double* d_qdes, double* d_vdes,
+                                      double* d_f_with_delta, double* d_ddq_res, double* d_feet, const double* d_q_filt,
+                                      const double* d_v_secu, double* d_result, int32_t* d_error_flag, void* stream) {
+  if (!h || !d_q || !d_dq || !d_f_cmd || !d_contacts || !d_pgoals || !d_vgoals || !d_agoals || !d_q_filt || !d_v_secu ||
+      !d_result)
+    return fail(-1, "qrw_wbc_compute_result: null argument");
+  qrw::WbcArgs a;
+  wbc_common(h, a);
+  a.mode = 0;
+  a.q = d_q; a.dq = d_dq; a.f_cmd = d_f_cmd; a.contacts = d_contacts;
+  a.pgoals = d_pgoals; a.vgoals = d_vgoals; a.agoals = d_agoals;
+  a.tau_ff = d_tau_ff; a.qdes = d_qdes; a.vdes = d_vdes; a.f_with_delta = d_f_with_delta;
+  a.ddq_res = d_ddq_res; a.feet = d_feet;
+  a.c_cs = h->ctrl_st; a.c_qfilt = d_q_filt; a.c_vsecu = d_v_secu; a.c_result = d_result; a.c_err = d_error_flag;
+  if (qrw::wbc_launch(a, (hipStream_t)stream) != 0)
+    return fail(-11, "qrw_wbc_compute_result: kernel launch failed", hipGetLastError());
+  return 0;
+}
+
 namespace {
 struct Stager {
   qrw_handle h;
@@ -605,4 +626,36 @@ extern "C" int qrw_stream_destroy(void* stream) {
   if (!stream) return 0;
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   return e == hipSuccess ? 0 : fail(-10, "qrw_stream_destroy: hipStreamDestroy failed", e);
+}
+
+// ------------------------------------------------------------------ fused head of a control iteration
+extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref, const double* d_q_filt,
+                               const double* d_v_filt, const double* d_rpy, const int32_t* d_code, int32_t code_scalar,
+                               const double* d_x_f_mpc, double* d_q, double* d_v, double* d_hv, double* d_vref,
+                               double* d_oRh_oTh, double* d_xref, double* d_fsteps, double* d_gait, double* d_target,
+                               double* d_feet_pva, double* d_contacts, double* d_x_f_wbc, double* d_q_wbc, double* d_b_v,
+                               double* d_f_cmd, double* d_feet_cmd, void* stream) {
+  if (!h || !h->plan_ready) return fail(-1, "qrw_control_pre: planner not initialised");
+  if (!d_joy_vref || !d_q_filt || !d_v_filt || !d_rpy || !d_q || !d_v || !d_hv || !d_vref || !d_xref || !d_feet_pva)
+    return fail(-1, "qrw_control_pre: null argument");
+  if (d_x_f_mpc && (!d_q_wbc || !d_b_v || !d_feet_cmd)) return fail(-1, "qrw_control_pre: null WBC target output");
+  qrw::ControllerArgs cu, cw;
+  ctrl_common(h, cu, qrw::kCtrlUpdateState);
+  cu.in0 = d_joy_vref; cu.in1 = d_q_filt; cu.in2 = d_v_filt; cu.in3 = d_rpy;
+  cu.out0 = d_q; cu.out1 = d_v; cu.out2 = d_hv; cu.out3 = d_vref; cu.out4 = d_oRh_oTh;
+  qrw::PlannerArgs p;
+  planner_common(h, p);
+  p.mode = qrw::kPlanGait | qrw::kPlanFootsteps | qrw::kPlanTraj | qrw::kPlanState;
+  p.k = k;
+  p.refresh = ((k % p.k_mpc) == 0 && k != 0) ? 1 : 0;
+  p.k_footsteps = p.k_mpc - k % p.k_mpc;
+  p.q7 = d_q; p.q_ld = 19; p.hv = d_hv; p.vref = d_vref; p.code = d_code; p.code_scalar = code_scalar;
+  p.xref = d_xref; p.fsteps = d_fsteps; p.gait = d_gait; p.target = d_target; p.feet_pva = d_feet_pva;
+  p.contacts = d_contacts;
+  ctrl_common(h, cw, qrw::kCtrlWbcInputs);
+  cw.in0 = d_x_f_mpc; cw.in1 = d_xref; cw.in2 = d_feet_pva; cw.in3 = d_v;
+  cw.out0 = d_x_f_wbc; cw.out1 = d_q_wbc; cw.out2 = d_b_v; cw.out3 = d_f_cmd; cw.out4 = d_feet_cmd;
+  if (qrw::control_pre_launch(cu, p, cw, d_x_f_mpc ? 1 : 0, (hipStream_t)stream) != 0)
+    return fail(-11, "qrw_control_pre: launch failed", hipGetLastError());
+  return 0;
 }

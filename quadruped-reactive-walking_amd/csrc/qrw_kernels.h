@@ -87,6 +87,11 @@ struct WbcArgs {
   int mode;
   const double *in0, *in1, *in2, *in3, *in4, *in5, *in6, *in7, *in8;
   double *out0, *out1, *out2, *out3, *out4;
+  // optional fused tail of a control iteration (Controller result + security_check, controller_glue.h)
+  double* c_cs;  // [kCtrlStItems][B] controller state, null = off
+  const double *c_qfilt, *c_vsecu;
+  double* c_result;
+  int32_t* c_err;
 };
 
 int wbc_launch(const WbcArgs& a, hipStream_t stream);
@@ -121,6 +126,8 @@ struct ControllerArgs {
   double* cs;  // [kCtrlStItems][B]
 };
 int controller_launch(const ControllerArgs& a, hipStream_t stream);
+int control_pre_launch(const ControllerArgs& cu, const PlannerArgs& p, const ControllerArgs& cw, int with_wbc_inputs,
+                       hipStream_t stream);
 int planner_item_offset(int N_gait, int which);
 int planner_launch(const PlannerArgs& a, hipStream_t stream);
 }

@@ -23,6 +23,7 @@
 
 #include "../../include/qrw_solo12_model.h"
 #include "qrw_device.h"
+#include "controller_glue.h"
 #include "qrw_kernels.h"
 
 namespace qrw {
@@ -824,6 +825,46 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       o[24 + 0 * 4 + j] = vf.x; o[24 + 1 * 4 + j] = vf.y; o[24 + 2 * 4 + j] = vf.z;
     }
     if (j == 0) { a.iters[bb] = it; a.status[bb] = stt; }
+    if (a.c_cs) {
+      // fused tail of the control iteration: Controller result + security_check (scripts/Controller.py:306-310,
+      // 341-365; same arithmetic as glue::result, one leg per lane, flags combined over the quad)
+      double* cs = a.c_cs + bb;
+      const size_t cB = (size_t)a.B;
+      int err = (int)cs[(size_t)glue::cERR * cB];
+      const double qd[3] = {q[0] + qs3.x, q[1] + qs3.y, q[2] + qs3.z};
+      const double vd[3] = {dqc3.x, dqc3.y, dqc3.z};
+      const double qsec[3] = {M_PI * 0.4, M_PI * 80 / 180, M_PI};
+      double e1 = 0.0, e2 = 0.0, e3 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        if (fabs(a.c_qfilt[bb * 19 + 7 + 3 * j + t]) > qsec[t]) e1 = 1.0;
+        if (fabs(a.c_vsecu[bb * 12 + 3 * j + t]) > 50) e2 = 1.0;
+        if (fabs(tff[t]) > 8) e3 = 1.0;
+      }
+      e1 = quad_max(e1); e2 = quad_max(e2); e3 = quad_max(e3);
+      if (err == 0) {  // the WBC counts this iteration: keep its references for the next one
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          cs[(size_t)(glue::cQDES + 3 * j + t) * cB] = qd[t];
+          cs[(size_t)(glue::cVDES + 3 * j + t) * cB] = vd[t];
+        }
+        if (e1 != 0.0) err = 1;
+        if (e2 != 0.0) err = 2;
+        if (e3 != 0.0) err = 3;
+        if (j == 0) cs[(size_t)glue::cERR * cB] = (double)err;
+      }
+      double* r = a.c_result + (size_t)bb * 60;  // P | D | q_des | v_des | tau_ff
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int i = 3 * j + t;
+        if (err == 0) {
+          r[i] = 3.0; r[12 + i] = 0.2; r[24 + i] = qd[t]; r[36 + i] = vd[t]; r[48 + i] = 0.8 * tff[t];
+        } else {
+          r[i] = 0.0; r[12 + i] = 0.1; r[24 + i] = 0.0; r[36 + i] = 0.0; r[48 + i] = 0.0;
+        }
+      }
+      if (j == 0 && a.c_err) a.c_err[bb] = err;
+    }
   }
 }
 

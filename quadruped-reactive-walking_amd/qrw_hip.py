@@ -65,6 +65,8 @@ SIGNATURES = {
     "qrw_controller_update_state": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_wbc_inputs": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_result": (C.c_int, [_vp] + [_vp] * 7 + [_vp]),
+    "qrw_control_pre": (C.c_int, [_vp, C.c_int32] + [_vp] * 4 + [_vp, C.c_int32, _vp] + [_vp] * 16 + [_vp]),
+    "qrw_wbc_compute_result": (C.c_int, [_vp] + [_vp] * 13 + [_vp] * 4 + [_vp]),
     "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "qrw_stream_destroy": (C.c_int, [_vp]),
     "qrw_device_cu_count": (C.c_int, [C.c_int32, _ip]),
@@ -409,6 +411,56 @@ class Batch:
             self._handle, self._dev(tau_ff, (B, 12)), self._dev(qdes, (B, 19)), self._dev(vdes, (B, 18)),
             self._dev(q_filt, (B, 19)), self._dev(v_secu, (B, 12)), self._dev(out["result"], (B, 5, 12)),
             _vp(out["error_flag"].data_ptr()), self._stream()), "qrw_controller_result")
+        return out
+
+    # ------------------------------------------------ fused control iteration (two launches + the MPC solve)
+    def control_pre(self, k, joy_v_ref, q_filt, v_filt, rpy, code=0, x_f_mpc=None, out=None):
+        """update_state + planner_step (+ controller_wbc_inputs when x_f_mpc is given) in one launch.
+        Returns one dict with the outputs of the three separate calls."""
+        import torch
+
+        B, N, Ng = self.B, self.N, self.N_gait
+        if out is None:
+            dev = q_filt.device
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+            out = dict(q=mk(B, 19), v=mk(B, 18), h_v=mk(B, 6), v_ref=mk(B, 6), oRh_oTh=mk(B, 12),
+                       xref=mk(B, 12, N + 1), fsteps=mk(B, Ng, 12), gait=mk(B, Ng, 4), target=mk(B, 3, 4),
+                       feet_pva=mk(B, 3, 3, 4), contacts=mk(B, 4),
+                       x_f_wbc=mk(B, 24), q_wbc=mk(B, 19), b_v=mk(B, 18), f_cmd=mk(B, 12), feet_cmd=mk(3, B, 3, 4))
+        cptr, cs = _vp(0), 0
+        if isinstance(code, torch.Tensor):
+            cptr = _vp(code.data_ptr())
+        else:
+            cs = int(code)
+        xf = _vp(0) if x_f_mpc is None else self._dev(x_f_mpc, (B, 24, N))
+        d = self._dev
+        _check(self._lib.qrw_control_pre(
+            self._handle, int(k), d(joy_v_ref, (B, 6)), d(q_filt, (B, 19)), d(v_filt, (B, 18)), d(rpy, (B, 3)), cptr, cs, xf,
+            d(out["q"], (B, 19)), d(out["v"], (B, 18)), d(out["h_v"], (B, 6)), d(out["v_ref"], (B, 6)),
+            d(out["oRh_oTh"], (B, 12)), d(out["xref"], (B, 12, N + 1)), d(out["fsteps"], (B, Ng, 12)),
+            d(out["gait"], (B, Ng, 4)), d(out["target"], (B, 3, 4)), d(out["feet_pva"], (B, 3, 3, 4)),
+            d(out["contacts"], (B, 4)), d(out["x_f_wbc"], (B, 24)), d(out["q_wbc"], (B, 19)), d(out["b_v"], (B, 18)),
+            d(out["f_cmd"], (B, 12)), d(out["feet_cmd"], (3, B, 3, 4)), self._stream()), "qrw_control_pre")
+        return out
+
+    def wbc_compute_result(self, q, dq, f_cmd, contacts, pgoals, vgoals, agoals, q_filt, v_secu, out=None):
+        """wbc_compute + controller_result in one launch; the dict also holds `result` (B,5,12) and `error_flag` (B,)."""
+        import torch
+
+        B = self.B
+        if out is None:
+            dev = q.device
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+            out = dict(tau_ff=mk(B, 12), qdes=mk(B, 19), vdes=mk(B, 18), f_with_delta=mk(B, 12), ddq_res=mk(B, 6),
+                       feet=mk(B, 3, 3, 4), result=mk(B, 5, 12),
+                       error_flag=torch.empty((B,), dtype=torch.int32, device=dev))
+        d = self._dev
+        _check(self._lib.qrw_wbc_compute_result(
+            self._handle, d(q, (B, 19)), d(dq, (B, 18)), d(f_cmd, (B, 12)), d(contacts, (B, 4)), d(pgoals, (B, 3, 4)),
+            d(vgoals, (B, 3, 4)), d(agoals, (B, 3, 4)), d(out["tau_ff"], (B, 12)), d(out["qdes"], (B, 19)),
+            d(out["vdes"], (B, 18)), d(out["f_with_delta"], (B, 12)), d(out["ddq_res"], (B, 6)), d(out["feet"], (B, 3, 3, 4)),
+            d(q_filt, (B, 19)), d(v_secu, (B, 12)), d(out["result"], (B, 5, 12)), _vp(out["error_flag"].data_ptr()),
+            self._stream()), "qrw_wbc_compute_result")
         return out
 
     # ------------------------------------------------ getters / diagnostics

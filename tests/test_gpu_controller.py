@@ -76,8 +76,9 @@ def test_glue_stages_match_oracle():
     assert [r.error_flag for r in refs] == [0, 1, 3, 3, 2, 0, 0]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "separate"])
 @pytest.mark.parametrize("mode", ["sync", "async_lag0", "async_lag3"])
-def test_closed_loop_matches_chained_oracles(oracle_mod, mode):
+def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
     """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
     made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state.  The
     asynchronous modes run the MPC on its own compute-unit-masked stream and adopt a result a fixed number of
@@ -86,10 +87,10 @@ def test_closed_loop_matches_chained_oracles(oracle_mod, mode):
     import controller_oracle as co
     from Controller import Controller_batch
 
-    B, iters = 5, (160 if mode == "sync" else 45)
+    B, iters = 5, (160 if (mode == "sync" and fused) else 45)
     lag = {"sync": 0, "async_lag0": 0, "async_lag3": 3}[mode]
     rng = np.random.default_rng(3)
-    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag)
+    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag, fused=fused)
     glue = [co.ControllerGlue(Q_INIT, 0.2229, 0.002) for _ in range(B)]
     plan = [oracle_mod.Planner() for _ in range(B)]
     mpc = [oracle_mod.MPC(0.02, 16, 0.32, 20) for _ in range(B)]
