@@ -230,10 +230,10 @@ int qrw_stream_destroy(void *stream);
 /* number of compute units of the device (256 on MI355X) */
 int qrw_device_cu_count(int32_t device, int32_t *n_cus);
 
-/* Diagnostic: checks on the device that v_mfma_f64_16x16x4_f64 accumulates a 12x12 matrix-vector product in the
- * operand layout the first version of the MPC sweeps used (the sweeps now run on the FP64 VALU with DPP row
- * broadcasts, csrc/chain_sweep.h). 0 = ok, 1 = layout mismatch, <0 = HIP error. *max_err may be NULL. */
-int qrw_selftest_mfma(double *max_err);
+/* Diagnostic: checks on the device what the MPC solver's linear algebra relies on — the row_newbcast form of
+ * v_fmac_f64, the twisted block sweeps in the production LDS layout and the in-register Gauss-Jordan inverse
+ * (csrc/chain_sweep.h) — against a host evaluation. 0 = ok, 1 = mismatch, <0 = HIP error. *max_err may be NULL. */
+int qrw_selftest_sweeps(double *max_err);
 
 /* workspace sizes, for callers that budget HBM */
 int64_t qrw_state_bytes(qrw_handle h);

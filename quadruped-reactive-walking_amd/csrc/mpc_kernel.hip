@@ -13,10 +13,10 @@
 // 6 of the 24N variables and 11 of the 44N constraints per lane — all ADMM vectors live in
 // registers.  The KKT solve (P + sigma I + A' R A) x = r is done by block elimination:
 //   1. forces f_k are eliminated per step inside each quad (12x12 inverse held as 3 rows per lane),
-//   2. the remaining block-tridiagonal system in the states (12x12 blocks, N steps) is solved by a
-//      block LDL' recursion whose two sequential sweeps run on the FP64 matrix cores
-//      (v_mfma_f64_16x16x4: y = c - N v with the 12-vector replicated across the 16 columns, so
-//      the D-layout of one step is exactly the B-operand of the next: no cross-lane traffic),
+//   2. the remaining block-tridiagonal system in the states (12x12 blocks, N steps) is solved by a twisted
+//      (two-ended) block LDL' recursion; factorisation and the two sequential sweeps run on the FP64 VALU with DPP
+//      row broadcasts (v_fmac_f64_dpp row_newbcast: lane i of a 16-lane row holds vector entry i and matrix row i;
+//      chain_sweep.h), both chains in one instruction stream,
 //   3. forces are back-substituted inside each quad.
 // LDS holds the N-1 chain matrices (column-major 12x12) and one 12N exchange vector.
 #include <hip/hip_runtime.h>
@@ -1127,70 +1127,77 @@ int mpc_launch(const MpcArgs& a, hipStream_t stream) {
 
 }  // namespace qrw
 
-// ---- self-test of the matrix-core operand layout the chain sweeps rely on --------------------
-// y = c + M v with M 12x12 (column-major), v replicated over the 16 B columns: every lane must end up
-// with y[4r + lane/16] in accumulator register r, which is also the B operand of the next step.
+// ---- self-test of what the solver's linear algebra relies on: v_fmac_f64_dpp row_newbcast semantics, the twisted
+// sweeps of chain_sweep.h in the production LDS layout and the in-register Gauss-Jordan inverse -------------------------
 namespace qrw {
-__global__ void mfma_layout_selftest_kernel(const double* M, const double* v, const double* c, double* y_out, int* bad) {
-  const int lane = threadIdx.x, mrow = lane & 15, mq = lane >> 4;
-  v4d acc;
-  acc[0] = c[mq]; acc[1] = c[4 + mq]; acc[2] = c[8 + mq]; acc[3] = 0.0;
+__global__ void sweeps_selftest_kernel(const double* M, const double* r, const double* G, double* out, double* ginv) {
+  __shared__ __attribute__((aligned(16))) double sN[16 * kSlot];
+  __shared__ double sX[18 * 12];
+  __shared__ double sDump[10 * 12];
+  const int lane = threadIdx.x;
+  for (int e = lane; e < 16 * kSlot; e += 64) sN[e] = M[e];
+  for (int e = lane; e < 18 * 12; e += 64) sX[e] = r[e];
+  __syncthreads();
+  chain_forward<16>(sN, sX, sDump, 16, lane);
+  __syncthreads();
+  chain_backward<16>(sN, sX, sDump, 16, lane);
+  __syncthreads();
+  for (int e = lane; e < 18 * 12; e += 64) out[e] = sX[e];
+  // two 12x12 inverses at once (DPP rows 0 and 1), rows 2-3 shadow them
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11, which = (lane >> 4) & 1;
+  double m[12];
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const double a = (mrow < 12) ? M[(4 * t + mq) * 12 + mrow] : 0.0;
-    const double bb = v[4 * t + mq];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-  }
-  // second, chained step with the previous D registers as B operand: y2 = c + M y
-  v4d acc2;
-  acc2[0] = c[mq]; acc2[1] = c[4 + mq]; acc2[2] = c[8 + mq]; acc2[3] = 0.0;
+  for (int c = 0; c < 12; c++) m[c] = G[which * 144 + i * 12 + c];
+  gj_invert12(m, i);
+  if (lane < 32 && (lane & 15) < 12)
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const double a = (mrow < 12) ? M[(4 * t + mq) * 12 + mrow] : 0.0;
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[t], acc2, 0, 0, 0);
-  }
-  if (mrow == 0) {
-    y_out[mq] = acc[0]; y_out[4 + mq] = acc[1]; y_out[8 + mq] = acc[2];
-    y_out[12 + mq] = acc2[0]; y_out[16 + mq] = acc2[1]; y_out[20 + mq] = acc2[2];
-  }
-  // every column must hold the same vector
-  const double ref0 = __shfl(acc2[0], mq * 16, 64), ref1 = __shfl(acc2[1], mq * 16, 64), ref2 = __shfl(acc2[2], mq * 16, 64);
-  if (acc2[0] != ref0 || acc2[1] != ref1 || acc2[2] != ref2) atomicAdd(bad, 1);
+    for (int c = 0; c < 12; c++) ginv[which * 144 + i * 12 + c] = m[c];
 }
 
-int mfma_selftest(double* max_err) {
-  double hM[144], hv[12], hc[12], hy[24], e1[12], e2[12];
-  for (int i = 0; i < 144; i++) hM[i] = 0.01 * ((i * 37) % 23) - 0.1;
-  for (int i = 0; i < 12; i++) { hv[i] = 0.3 * i - 1.0; hc[i] = 0.05 * i + 0.2; }
-  for (int r = 0; r < 12; r++) {
-    double s = hc[r];
-    for (int k = 0; k < 12; k++) s += hM[k * 12 + r] * hv[k];
-    e1[r] = s;
-  }
-  for (int r = 0; r < 12; r++) {
-    double s = hc[r];
-    for (int k = 0; k < 12; k++) s += hM[k * 12 + r] * e1[k];
-    e2[r] = s;
-  }
-  double *dM, *dv, *dc, *dy;
-  int* dbad;
-  int hbad = 0;
+int sweeps_selftest(double* max_err) {
+  constexpr int N = 16, m = N / 2;
+  static double hM[16 * kSlot], hr[18 * 12], hout[18 * 12], hG[288], hGi[288];
+  for (int e = 0; e < 16 * kSlot; e++) hM[e] = 0.0;
+  for (int s = 0; s < N - 1; s++)
+    for (int i = 0; i < 12; i++)
+      for (int c = 0; c < 12; c++) hM[s * kSlot + c * kCol + i] = 0.25 * sin(0.37 * (s * 144 + i * 12 + c) + 1.0);
+  for (int e = 0; e < 18 * 12; e++) hr[e] = 0.0;
+  for (int k = 0; k < N; k++)
+    for (int i = 0; i < 12; i++) hr[chain_pos(k, m, N) * 12 + i] = cos(0.11 * (k * 12 + i));
+  for (int w = 0; w < 2; w++)  // diagonally dominant test matrices
+    for (int i = 0; i < 12; i++)
+      for (int c = 0; c < 12; c++) hG[w * 144 + i * 12 + c] = ((i == c) ? 4.0 + w : 0.0) + 0.3 * sin(1.7 * (w * 144 + i * 12 + c));
+  // host evaluation of the same recursions (forward, then backward on its result)
+  auto Mat = [&](int slot, int i, int c) { return hM[slot * kSlot + c * kCol + i]; };
+  double u[N][12], t[12];
+  for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) u[k][i] = hr[chain_pos(k, m, N) * 12 + i];
+  for (int k = 1; k < m; k++) for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(k - 1, i, c) * u[k - 1][c]; u[k][i] = s; }
+  for (int k = N - 2; k > m; k--) { for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(m + N - 2 - k, i, c) * u[k + 1][c]; t[i] = s; } for (int i = 0; i < 12; i++) u[k][i] = t[i]; }
+  for (int i = 0; i < 12; i++) { double s = u[m][i], s2 = 0; for (int c = 0; c < 12; c++) { s += Mat(m - 1, i, c) * u[m - 1][c]; s2 += Mat(N - 2, i, c) * u[m + 1][c]; } t[i] = s + s2; }
+  for (int i = 0; i < 12; i++) u[m][i] = t[i];
+  for (int k = m - 1; k >= 0; k--) { for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(k, c, i) * u[k + 1][c]; t[i] = s; } for (int i = 0; i < 12; i++) u[k][i] = t[i]; }
+  for (int k = m + 1; k < N; k++) { for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(m + N - 2 - (k - 1), c, i) * u[k - 1][c]; t[i] = s; } for (int i = 0; i < 12; i++) u[k][i] = t[i]; }
+  double *dM, *dr, *dG, *dout, *dGi;
   if (hipMalloc((void**)&dM, sizeof(hM)) != hipSuccess) return -1;
-  hipMalloc((void**)&dv, sizeof(hv)); hipMalloc((void**)&dc, sizeof(hc)); hipMalloc((void**)&dy, sizeof(hy));
-  hipMalloc((void**)&dbad, sizeof(int));
-  hipMemcpy(dM, hM, sizeof(hM), hipMemcpyHostToDevice); hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice);
-  hipMemcpy(dc, hc, sizeof(hc), hipMemcpyHostToDevice); hipMemset(dbad, 0, sizeof(int));
-  hipLaunchKernelGGL(mfma_layout_selftest_kernel, dim3(1), dim3(64), 0, 0, dM, dv, dc, dy, dbad);
+  hipMalloc((void**)&dr, sizeof(hr)); hipMalloc((void**)&dG, sizeof(hG)); hipMalloc((void**)&dout, sizeof(hout));
+  hipMalloc((void**)&dGi, sizeof(hGi));
+  hipMemcpy(dM, hM, sizeof(hM), hipMemcpyHostToDevice); hipMemcpy(dr, hr, sizeof(hr), hipMemcpyHostToDevice);
+  hipMemcpy(dG, hG, sizeof(hG), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(sweeps_selftest_kernel, dim3(1), dim3(64), 0, 0, dM, dr, dG, dout, dGi);
   hipError_t e = hipDeviceSynchronize();
-  hipMemcpy(hy, dy, sizeof(hy), hipMemcpyDeviceToHost); hipMemcpy(&hbad, dbad, sizeof(int), hipMemcpyDeviceToHost);
-  hipFree(dM); hipFree(dv); hipFree(dc); hipFree(dy); hipFree(dbad);
+  hipMemcpy(hout, dout, sizeof(hout), hipMemcpyDeviceToHost); hipMemcpy(hGi, dGi, sizeof(hGi), hipMemcpyDeviceToHost);
+  hipFree(dM); hipFree(dr); hipFree(dG); hipFree(dout); hipFree(dGi);
   if (e != hipSuccess) return -2;
-  double me = 0;
-  for (int r = 0; r < 12; r++) {
-    me = fmax(me, fabs(hy[r] - e1[r]));
-    me = fmax(me, fabs(hy[12 + r] - e2[r]));
-  }
+  double me = 0.0;
+  for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) me = fmax(me, fabs(hout[chain_pos(k, m, N) * 12 + i] - u[k][i]) / 8.0);
+  for (int w = 0; w < 2; w++)  // G * G^-1 = I
+    for (int i = 0; i < 12; i++)
+      for (int c = 0; c < 12; c++) {
+        double s = 0.0;
+        for (int q = 0; q < 12; q++) s += hG[w * 144 + i * 12 + q] * hGi[w * 144 + q * 12 + c];
+        me = fmax(me, fabs(s - ((i == c) ? 1.0 : 0.0)));
+      }
   if (max_err) *max_err = me;
-  return (hbad == 0 && me < 1e-12) ? 0 : 1;
+  return (me < 1e-12) ? 0 : 1;
 }
 }  // namespace qrw

@@ -442,10 +442,10 @@ extern "C" int qrw_get_base_inertia_diag(qrw_handle h, double* h_Y6) {
   return 0;
 }
 
-extern "C" int qrw_selftest_mfma(double* max_err) {
+extern "C" int qrw_selftest_sweeps(double* max_err) {
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_mfma: no HIP device");
-  return qrw::mfma_selftest(max_err);
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_sweeps: no HIP device");
+  return qrw::sweeps_selftest(max_err);
 }
 
 // Diagnostic (profiling builds only, -DQRW_PROFILE_PHASES): per-instance shader-clock totals of the MPC kernel phases.

@@ -99,7 +99,7 @@ int wbc_launch(const WbcArgs& a, hipStream_t stream);
 }  // namespace qrw
 
 namespace qrw {
-int mfma_selftest(double* max_err);
+int sweeps_selftest(double* max_err);
 
 // ---- planners (planner_kernel.hip)
 enum PlannerMode { kPlanInit = 1, kPlanGait = 2, kPlanFootsteps = 4, kPlanTraj = 8, kPlanState = 16, kPlanOutputs = 32 };

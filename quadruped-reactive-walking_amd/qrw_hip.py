@@ -70,7 +70,7 @@ SIGNATURES = {
     "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "qrw_stream_destroy": (C.c_int, [_vp]),
     "qrw_device_cu_count": (C.c_int, [C.c_int32, _ip]),
-    "qrw_selftest_mfma": (C.c_int, [_dp]),
+    "qrw_selftest_sweeps": (C.c_int, [_dp]),
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
 
@@ -147,9 +147,9 @@ class CuStream:
             pass
 
 
-def selftest_mfma():
+def selftest_sweeps():
     err = C.c_double(0.0)
-    rc = load_library().qrw_selftest_mfma(C.byref(err))
+    rc = load_library().qrw_selftest_sweeps(C.byref(err))
     return rc, err.value
 
 

@@ -40,10 +40,10 @@ def run_sequence(oracle_mod, synth_mod, B, N, gaits, steps, seed0, closed_loop=T
     return eng, refs, worst
 
 
-def test_mfma_layout_selftest():
+def test_sweeps_selftest():
     import qrw_hip
 
-    rc, err = qrw_hip.selftest_mfma()
+    rc, err = qrw_hip.selftest_sweeps()
     assert rc == 0 and err < 1e-12
 
 
