@@ -159,4 +159,56 @@ __device__ __forceinline__ void chain_backward(const double* sN, double* sX, dou
   }
 }
 
+// ---- in-register Gauss-Jordan on the FP64 VALU: lane i of a 16-lane DPP row holds row i of a 12x12 matrix in m[0..11]
+// One pivot: every row gets  m[c] += m_P[c] * f  with m_P[c] read from lane P by row_newbcast (f = -m[P]/pivot for the
+// other rows, 1/pivot - 1 for row P itself), then column P is replaced.  12 pivots invert the matrix in place.
+#define QRW_GJ_FM(C) "v_fmac_f64_dpp %" #C ", %" #C ", %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+template <int P>
+__device__ __forceinline__ void gj_pivot(double (&m)[12], int i) {
+  double piv = 0.0;
+  const double one = 1.0;
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(piv) : "v"(m[P]), "v"(one), "n"(P));
+  const double d = 1.0 / piv;
+  const double f = (i == P) ? (d - 1.0) : (-m[P] * d);
+  asm("s_nop 1\n\t" QRW_GJ_FM(0) QRW_GJ_FM(1) QRW_GJ_FM(2) QRW_GJ_FM(3) QRW_GJ_FM(4) QRW_GJ_FM(5) QRW_GJ_FM(6) QRW_GJ_FM(7)
+      QRW_GJ_FM(8) QRW_GJ_FM(9) QRW_GJ_FM(10) QRW_GJ_FM(11)
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]),
+        "+v"(m[9]), "+v"(m[10]), "+v"(m[11])
+      : "v"(f), "n"(P));
+  m[P] = (i == P) ? d : f;
+}
+#undef QRW_GJ_FM
+__device__ __forceinline__ void gj_invert12(double (&m)[12], int i) {
+  gj_pivot<0>(m, i); gj_pivot<1>(m, i); gj_pivot<2>(m, i); gj_pivot<3>(m, i); gj_pivot<4>(m, i); gj_pivot<5>(m, i);
+  gj_pivot<6>(m, i); gj_pivot<7>(m, i); gj_pivot<8>(m, i); gj_pivot<9>(m, i); gj_pivot<10>(m, i); gj_pivot<11>(m, i);
+}
+// acc[c] += m_J[c] * coef for c = 0..11 (row J of the matrix held across the lanes, coef per lane)
+template <int J>
+__device__ __forceinline__ void row_bcast_fma(double (&acc)[12], const double (&m)[12], double coef) {
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %12, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %13, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %14, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %15, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %16, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %17, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %18, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %19, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %8, %20, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %9, %21, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %10, %22, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %11, %23, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+        "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
+      : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]),
+        "v"(m[10]), "v"(m[11]), "v"(coef), "n"(J));
+}
+// value of the same register six lanes below in the 16-lane row (0 where there is none)
+__device__ __forceinline__ double row_shr6(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x116, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x116, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 }  // namespace qrw
