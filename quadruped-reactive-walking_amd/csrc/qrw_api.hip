@@ -471,6 +471,7 @@ static void planner_common(qrw_handle h, qrw::PlannerArgs& a) {
 extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void* stream) {
   if (!h || !pc) return fail(-1, "qrw_planner_init: null argument");
   if (pc->k_mpc < 1) return fail(-1, "qrw_planner_init: k_mpc must be >= 1");
+  if (h->cfg.N_gait > 63) return fail(-1, "qrw_planner_init: N_gait must be <= 63 (gait matrices are 64-bit column masks)");
   // Gait::initialize throws when the matrices are too small (src/Gait.cpp:30-31)
   const long per = lround(h->cfg.T_gait / h->cfg.dt_mpc);
   if (h->cfg.n_steps > h->cfg.N_gait || per > h->cfg.N_gait || h->cfg.n_steps + 1 > h->cfg.N_gait)
