@@ -16,12 +16,12 @@ def makespan(order, w, slots=1024):
     return max(h)
 
 B, N = 4096, 16
-sb = synth.SyntheticBatch(B, N)
+sb = synth.SyntheticBatch(B, N, n_seq=48)
 g = qrw_hip.Batch(B, N)
 prev = None
 hist = []
 tot = {}
-for s in range(16):
+for s in range(44):
     d = sb.step(s)
     g.mpc_solve_host(d["xref"], d["fsteps"], s)
     it = g.mpc_stats()["iters"].astype(float) + 9.0  # + setup/factor overhead in iteration units
@@ -33,10 +33,16 @@ for s in range(16):
         if len(hist) >= 3:
             preds = {"prev": prev, "max2": np.maximum(hist[-1], hist[-2]), "max3": np.maximum(np.maximum(hist[-1], hist[-2]), hist[-3]),
                      "mean3": (hist[-1] + hist[-2] + hist[-3]) / 3, "ema": 0.5 * hist[-1] + 0.3 * hist[-2] + 0.2 * hist[-3]}
+            if len(hist) >= 16:
+                preds["period16"] = hist[-16]
+                preds["max(prev,period16)"] = np.maximum(hist[-1], hist[-16])
+                preds["mean(prev,period16)"] = 0.5 * (hist[-1] + hist[-16])
+            if len(hist) >= 32:
+                preds["mean(p16,p32)"] = 0.5 * (hist[-16] + hist[-32])
             for kk, pv in preds.items():
                 tot.setdefault(kk, []).append(makespan(np.argsort(-pv, kind="stable"), it) / lb)
             tot.setdefault("actual", []).append(b / lb)
-        print("step %d: mean %.0f max %.0f | lower bound %.0f | order by previous counts %.0f (%.2fx) | by actual counts %.0f (%.2fx) | index order %.0f (%.2fx) | corr(prev,cur) %.3f"
+        if s % 8 == 0: print("step %d: mean %.0f max %.0f | lower bound %.0f | order by previous counts %.0f (%.2fx) | by actual counts %.0f (%.2fx) | index order %.0f (%.2fx) | corr(prev,cur) %.3f"
               % (s, it.mean(), it.max(), lb, a, a / lb, b, b / lb, c, c / lb, np.corrcoef(prev, it)[0, 1]))
     prev = it
     hist.append(it)
