@@ -1036,16 +1036,18 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 }
 
 // Counting sort of the instances by decreasing iteration count (multiples of 25, at most 4000) -> order[]
-__global__ __launch_bounds__(1024) void mpc_order_kernel(const int* iters, int* hist1, int* hist2, int* order, int B) {
-  // key = the largest of the last three solves' iteration counts (a slightly better predictor of the next one than
-  // the last alone: the simulated makespan, scripts/gpu_lpt_sim.py, drops from 1.17x to 1.14x of the lower bound)
+__global__ __launch_bounds__(1024) void mpc_order_kernel(const int* iters, float* ema, int* order, int B) {
+  // key = exponential moving average (1/8) of the instance's iteration counts: a better predictor of the next solve
+  // than the last count alone (simulated makespan, scripts/gpu_lpt_sim.py: 1.12x instead of 1.17x of the lower bound)
   __shared__ int hist[162];
   __shared__ int offs[162];
   for (int i = threadIdx.x; i < 162; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b], h1 = hist1[b], h2 = hist2[b];
-    int key = max(it, max(h1, h2)) / 25;
+    const float it = (float)iters[b], e0 = ema[b];
+    const float e = (e0 == 0.0f) ? it : e0 + (it - e0) * 0.125f;
+    ema[b] = e;
+    int key = (int)(e * 0.04f);
     key = key < 0 ? 0 : (key > 160 ? 160 : key);
     atomicAdd(&hist[key], 1);
   }
@@ -1056,17 +1058,14 @@ __global__ __launch_bounds__(1024) void mpc_order_kernel(const int* iters, int* 
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b], h1 = hist1[b], h2 = hist2[b];
-    int key = max(it, max(h1, h2)) / 25;
+    int key = (int)(ema[b] * 0.04f);
     key = key < 0 ? 0 : (key > 160 ? 160 : key);
     order[atomicAdd(&offs[key], 1)] = b;
-    hist2[b] = h1;
-    hist1[b] = it;
   }
 }
 
-int mpc_order_launch(const int* iters, int* hist1, int* hist2, int* order, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, iters, hist1, hist2, order, B);
+int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, iters, ema, order, B);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

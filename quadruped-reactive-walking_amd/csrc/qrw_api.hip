@@ -40,7 +40,7 @@ struct qrw_handle_s {
   int* mpc_gait = nullptr;
   int* mpc_flags = nullptr;
   int *mpc_iters = nullptr, *mpc_status = nullptr, *mpc_rho_updates = nullptr, *mpc_order = nullptr;
-  int *mpc_hist1 = nullptr, *mpc_hist2 = nullptr;  // iteration counts of the two solves before the last
+  float* mpc_ema = nullptr;  // moving average of each instance's iteration counts (longest-first block order)
   bool mpc_have_order = false;
   double *mpc_rho = nullptr, *mpc_pri = nullptr, *mpc_dua = nullptr, *mpc_prof = nullptr;
   // WBC
@@ -127,8 +127,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->mpc_status, B * sizeof(int));
   ALLOC(h->mpc_rho_updates, B * sizeof(int));
   ALLOC(h->mpc_order, B * sizeof(int));
-  ALLOC(h->mpc_hist1, B * sizeof(int));
-  ALLOC(h->mpc_hist2, B * sizeof(int));
+  ALLOC(h->mpc_ema, B * sizeof(float));
   ALLOC(h->mpc_rho, B * sizeof(double));
   ALLOC(h->mpc_pri, B * sizeof(double));
   ALLOC(h->mpc_dua, B * sizeof(double));
@@ -152,7 +151,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
 extern "C" int qrw_destroy(qrw_handle h) {
   if (!h) return 0;
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
-  hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_hist1); hipFree(h->mpc_hist2); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
+  hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_ema); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
   hipFree(h->plan_st); hipFree(h->ctrl_st);
   hipFree(h->stage); hipFree(h->stage_i);
@@ -180,7 +179,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
   if (h->cfg.batch > 1024) {
-    if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_hist1, h->mpc_hist2, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
+    if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_ema, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: order kernel launch failed", hipGetLastError());
     h->mpc_have_order = true;
   }

@@ -60,7 +60,7 @@ struct MpcArgs {
 };
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
-int mpc_order_launch(const int* iters, int* hist1, int* hist2, int* order, int B, hipStream_t stream);
+int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_t stream);
 
 // WBC persistent state: st[instance][item]
 enum WbcStateItem {

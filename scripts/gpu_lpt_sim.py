@@ -20,6 +20,7 @@ sb = synth.SyntheticBatch(B, N, n_seq=48)
 g = qrw_hip.Batch(B, N)
 prev = None
 hist = []
+ema = {}
 tot = {}
 for s in range(44):
     d = sb.step(s)
@@ -37,6 +38,20 @@ for s in range(44):
                 preds["period16"] = hist[-16]
                 preds["max(prev,period16)"] = np.maximum(hist[-1], hist[-16])
                 preds["mean(prev,period16)"] = 0.5 * (hist[-1] + hist[-16])
+            for a_ in (4, 8, 16):
+                if a_ in ema:
+                    preds["ema%d" % a_] = ema[a_]
+                    preds["max(prev,ema%d)" % a_] = np.maximum(prev, ema[a_])
+            if len(hist) >= 5:
+                preds["max5"] = np.max(np.stack(hist[-5:]), 0)
+            if len(hist) >= 8:
+                preds["max8"] = np.max(np.stack(hist[-8:]), 0)
+                preds["mean8"] = np.mean(np.stack(hist[-8:]), 0)
+                preds["p90_8"] = np.percentile(np.stack(hist[-8:]), 90, axis=0)
+            if len(hist) >= 16:
+                preds["max16"] = np.max(np.stack(hist[-16:]), 0)
+                preds["mean16"] = np.mean(np.stack(hist[-16:]), 0)
+                preds["max(max3,p16)"] = np.maximum(preds["max3"], hist[-16])
             if len(hist) >= 32:
                 preds["mean(p16,p32)"] = 0.5 * (hist[-16] + hist[-32])
             for kk, pv in preds.items():
@@ -44,6 +59,8 @@ for s in range(44):
             tot.setdefault("actual", []).append(b / lb)
         if s % 8 == 0: print("step %d: mean %.0f max %.0f | lower bound %.0f | order by previous counts %.0f (%.2fx) | by actual counts %.0f (%.2fx) | index order %.0f (%.2fx) | corr(prev,cur) %.3f"
               % (s, it.mean(), it.max(), lb, a, a / lb, b, b / lb, c, c / lb, np.corrcoef(prev, it)[0, 1]))
+    for a_ in (4, 8, 16):
+        ema[a_] = it.copy() if a_ not in ema else ema[a_] + (it - ema[a_]) / a_
     prev = it
     hist.append(it)
 print({k: round(float(np.mean(v)), 3) for k, v in tot.items()})
