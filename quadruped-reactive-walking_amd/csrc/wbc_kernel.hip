@@ -781,6 +781,28 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       gamma[i] = (1.0 / a.Y[i]) * (xf[i] - rnea6[i]);
     }
   }
+  // everything that does not depend on the QP leaves now, and the leg kinematics / base rotation are recomputed after
+  // the solve instead of being carried across it: the ADMM loop needs most of the register file for itself
+  if (valid) {
+    if (a.qdes) {
+      double* o = a.qdes + bb * 19;
+      if (j == 0) for (int i = 0; i < 7; i++) o[i] = 0.0;  // q_cmd[:7] is never written (solo12InvKin.py:67)
+      o[7 + 3 * j] = q[0] + qs3.x; o[8 + 3 * j] = q[1] + qs3.y; o[9 + 3 * j] = q[2] + qs3.z;
+    }
+    if (a.vdes) {
+      double* o = a.vdes + bb * 18;
+      if (j == 0) for (int i = 0; i < 6; i++) o[i] = 0.0;
+      o[6 + 3 * j] = dqc3.x; o[7 + 3 * j] = dqc3.y; o[8 + 3 * j] = dqc3.z;
+    }
+    if (a.feet) {  // feet_pos, feet_err, feet_vel as 3x4 each (QP_WBC.py:73-80)
+      double* o = a.feet + (size_t)bb * 36;
+      o[0 * 4 + j] = K.pf.x; o[1 * 4 + j] = K.pf.y; o[2 * 4 + j] = K.pf.z;
+      o[12 + 0 * 4 + j] = perr.x; o[12 + 1 * 4 + j] = perr.y; o[12 + 2 * 4 + j] = perr.z;
+      o[24 + 0 * 4 + j] = vf.x; o[24 + 1 * 4 + j] = vf.y; o[24 + 2 * 4 + j] = vf.z;
+    }
+  }
+  const double qd_leg[3] = {q[0] + qs3.x, q[1] + qs3.y, q[2] + qs3.z};
+  const double vd_leg[3] = {dqc3.x, dqc3.y, dqc3.z};
   QpIo io;
   qp_build(Aj, gamma, fc, j, io);
   double sol[3];
@@ -792,38 +814,42 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   const double fw[3] = {sol[0] + fc[0], sol[1] + fc[1], sol[2] + fc[2]};
   // second rnea with the base acceleration found by the QP (QP_WBC.py:110-116); only [6:] is used
   const V3 alb = mk(dd[3], dd[4], dd[5]);
-  const V3 ab1 = ab0 + mk(dd[0], dd[1], dd[2]);
-  double tau2[3];
-  leg_newton_euler(C, K, dq, ddq, wb, alb, ab1, Fl, Ml, tau2);
-  // tau_ff = RNEA_delta - Jc[:, 6:]' f (QP_WBC.py:117): Jc joint block of a stance foot = Rb J_leg
-  double tff[3];
+  double tau2[3], tff[3];
   {
-    const V3 fbv = mulT(Rb, mk(fw[0], fw[1], fw[2]));  // Rb' f
-    tff[0] = tau2[0] - (stance ? dot(K.J0, fbv) : 0.0);
-    tff[1] = tau2[1] - (stance ? dot(K.J1, fbv) : 0.0);
-    tff[2] = tau2[2] - (stance ? dot(K.J2, fbv) : 0.0);
+    // recomputed (not carried across the solve): joint angles and quaternion are re-read so that the compiler cannot
+    // merge these with the first evaluation
+    double q2[3], qq[4];
+#pragma unroll
+    for (int t = 0; t < 3; t++) q2[t] = qv[7 + 3 * j + t];
+#pragma unroll
+    for (int t = 0; t < 4; t++) qq[t] = qv[3 + t];
+    asm volatile("" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]));
+    const LegKin K2 = leg_kinematics(C, q2);
+    M3 Rb2;
+    {
+      const double x = qq[0], y = qq[1], z = qq[2], w = qq[3];
+      const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                   tyz = tz * y, tzz = tz * z;
+      Rb2.r0 = mk(1 - (tyy + tzz), txy - twz, txz + twy);
+      Rb2.r1 = mk(txy + twz, 1 - (txx + tzz), tyz - twx);
+      Rb2.r2 = mk(txz - twy, tyz + twx, 1 - (txx + tyy));
+    }
+    const V3 grav2 = mulT(Rb2, mk(0.0, 0.0, QRW_SOLO12_MODEL.gravity));
+    const V3 ab02 = grav2 + cross(wb, vb);
+    const V3 ab1 = ab02 + mk(dd[0], dd[1], dd[2]);
+    leg_newton_euler(C, K2, dq, ddq, wb, alb, ab1, Fl, Ml, tau2);
+    // tau_ff = RNEA_delta - Jc[:, 6:]' f (QP_WBC.py:117): Jc joint block of a stance foot = Rb J_leg
+    const V3 fbv = mulT(Rb2, mk(fw[0], fw[1], fw[2]));  // Rb' f
+    tff[0] = tau2[0] - (stance ? dot(K2.J0, fbv) : 0.0);
+    tff[1] = tau2[1] - (stance ? dot(K2.J1, fbv) : 0.0);
+    tff[2] = tau2[2] - (stance ? dot(K2.J2, fbv) : 0.0);
   }
   if (valid) {
     if (a.tau_ff) { double* o = a.tau_ff + bb * 12 + 3 * j; o[0] = tff[0]; o[1] = tff[1]; o[2] = tff[2]; }
-    if (a.qdes) {
-      double* o = a.qdes + bb * 19;
-      if (j == 0) for (int i = 0; i < 7; i++) o[i] = 0.0;  // q_cmd[:7] is never written (solo12InvKin.py:67)
-      o[7 + 3 * j] = q[0] + qs3.x; o[8 + 3 * j] = q[1] + qs3.y; o[9 + 3 * j] = q[2] + qs3.z;
-    }
-    if (a.vdes) {
-      double* o = a.vdes + bb * 18;
-      if (j == 0) for (int i = 0; i < 6; i++) o[i] = 0.0;
-      o[6 + 3 * j] = dqc3.x; o[7 + 3 * j] = dqc3.y; o[8 + 3 * j] = dqc3.z;
-    }
     if (a.f_with_delta) { double* o = a.f_with_delta + bb * 12 + 3 * j; o[0] = fw[0]; o[1] = fw[1]; o[2] = fw[2]; }
     if (a.ddq_res && j == 0)
       for (int i = 0; i < 6; i++) a.ddq_res[bb * 6 + i] = dd[i];
-    if (a.feet) {  // feet_pos, feet_err, feet_vel as 3x4 each (QP_WBC.py:73-80)
-      double* o = a.feet + (size_t)bb * 36;
-      o[0 * 4 + j] = K.pf.x; o[1 * 4 + j] = K.pf.y; o[2 * 4 + j] = K.pf.z;
-      o[12 + 0 * 4 + j] = perr.x; o[12 + 1 * 4 + j] = perr.y; o[12 + 2 * 4 + j] = perr.z;
-      o[24 + 0 * 4 + j] = vf.x; o[24 + 1 * 4 + j] = vf.y; o[24 + 2 * 4 + j] = vf.z;
-    }
     if (j == 0) { a.iters[bb] = it; a.status[bb] = stt; }
     if (a.c_cs) {
       // fused tail of the control iteration: Controller result + security_check (scripts/Controller.py:306-310,
@@ -831,8 +857,8 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       double* cs = a.c_cs + bb;
       const size_t cB = (size_t)a.B;
       int err = (int)cs[(size_t)glue::cERR * cB];
-      const double qd[3] = {q[0] + qs3.x, q[1] + qs3.y, q[2] + qs3.z};
-      const double vd[3] = {dqc3.x, dqc3.y, dqc3.z};
+      const double qd[3] = {qd_leg[0], qd_leg[1], qd_leg[2]};
+      const double vd[3] = {vd_leg[0], vd_leg[1], vd_leg[2]};
       const double qsec[3] = {M_PI * 0.4, M_PI * 80 / 180, M_PI};
       double e1 = 0.0, e2 = 0.0, e3 = 0.0;
 #pragma unroll
