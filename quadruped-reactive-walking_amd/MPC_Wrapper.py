@@ -105,21 +105,26 @@ class MPC_Wrapper:
         else:
             self.run_MPC_synchronous(k, xref, fsteps)
 
+        # Bookkeeping of the default result (:89-102): past the first iterations the force rows are shifted one horizon
+        # step to the left (the slice 12:12+n_steps of a 24-row array is rows 12..23), and when the last gait row is in
+        # another phase than the first one the freed last column gets the static share m g / n_contacts on its stance feet.
+        gait = np.asarray(gait)
         if k > 2:
-            self.last_available_result[12:(12 + self.n_steps), :] = np.roll(
-                self.last_available_result[12:(12 + self.n_steps), :], -1, axis=1)
-
-        pt = 0
-        while (np.any(gait[pt, :])):
-            pt += 1
-        if k > 2 and not np.array_equal(gait[0, :], gait[pt - 1, :]):
-            mass = 2.5
-            nb_ctc = np.sum(gait[pt - 1, :])
-            F = 9.81 * mass / nb_ctc
-            self.last_available_result[12:, self.n_steps - 1] = np.zeros(12)
-            for i in range(4):
-                if (gait[pt - 1, i] == 1):
-                    self.last_available_result[12 + 3 * i + 2, self.n_steps - 1] = F
+            forces = self.last_available_result[12:(12 + self.n_steps), :]
+            forces[:] = np.roll(forces, -1, axis=1)
+            n_rows = 0  # rows until the first all-zero one
+            while np.any(gait[n_rows, :]):
+                n_rows += 1
+            last_row = gait[n_rows - 1, :]
+            if not np.array_equal(gait[0, :], last_row):
+                share = 9.81 * 2.5 / np.sum(last_row)
+                col = np.zeros(12)
+                col[2::3] = np.where(last_row == 1, share, 0.0)
+                self.last_available_result[12:, self.n_steps - 1] = col
+        else:
+            n_rows = 0
+            while np.any(gait[n_rows, :]):  # the reference scans the gait on every call (IndexError if it has no zero row)
+                n_rows += 1
         return 0
 
     def get_latest_result(self):

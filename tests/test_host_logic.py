@@ -66,3 +66,31 @@ def test_quaternion_to_rpy():
     assert np.allclose(MPC_Wrapper.quaternionToRPY(q).ravel(), [0, 0, a])
     q = [np.sin(a / 2), 0, 0, np.cos(a / 2)]
     assert np.allclose(MPC_Wrapper.quaternionToRPY(q).ravel(), [a, 0, 0])
+
+
+def test_mpc_wrapper_default_result_bookkeeping(synth_mod):
+    """MPC_Wrapper.solve (scripts/MPC_Wrapper.py:89-102): shift of the stored force rows and the m g / n_contacts
+    column, checked against a direct statement of those lines on a few gait matrices (no GPU: the solver call is stubbed)."""
+    import MPC_Wrapper as mw
+
+    rng = np.random.default_rng(5)
+    for name in ("trot", "walk", "static"):
+        gait = np.zeros((20, 4))
+        gait[:16] = np.roll(synth_mod.gait_pattern(name, 16), -3, axis=0)
+        w = mw.MPC_Wrapper.__new__(mw.MPC_Wrapper)
+        w.multiprocessing, w.n_steps = False, 16
+        w.run_MPC_synchronous = lambda *a: None
+        w.last_available_result = rng.uniform(-1, 1, (24, 16))
+        for k in (0, 2, 3, 40):
+            before = w.last_available_result.copy()
+            assert w.solve(k, None, None, gait) == 0
+            exp = before.copy()
+            if k > 2:
+                exp[12:24] = np.roll(before[12:24], -1, axis=1)
+                last = gait[15]
+                if not np.array_equal(gait[0], last):
+                    exp[12:, 15] = 0.0
+                    for i in range(4):
+                        if last[i] == 1:
+                            exp[12 + 3 * i + 2, 15] = 9.81 * 2.5 / last.sum()
+            assert np.array_equal(w.last_available_result, exp), (name, k)
