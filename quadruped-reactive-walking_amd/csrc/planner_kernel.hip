@@ -36,9 +36,11 @@ struct Lay {  // item offsets for a given N_gait
 __host__ __device__ inline Lay make_layout(int Ng) {
   Lay L;
   int o = 0;
-  L.past = o; o += Ng * 4;
-  L.cur = o; o += Ng * 4;
-  L.des = o; o += Ng * 4;
+  // gait matrices: four 64-bit column masks each, kept bit-for-bit in double-sized state items (12 items instead of
+  // 3 * N_gait * 4 doubles: one round trip to HBM instead of fifteen)
+  L.past = o; o += 4;
+  L.cur = o; o += 4;
+  L.des = o; o += 4;
   L.cf = o; o += 12;
   L.fs = o; o += Ng * 12;
   L.tgt = o; o += 12;
@@ -65,7 +67,7 @@ __host__ __device__ inline Lay make_layout(int Ng) {
 // The reference keeps the three gait matrices (past / current / desired, N_gait x 4 entries that are only ever
 // 0 or 1) as dense double matrices and rolls them with chains of row swaps; run literally against HBM that is
 // thousands of dependent memory round trips per control iteration.  Here a matrix is four 64-bit column masks in
-// registers (bit i = row i), unpacked from / packed back into the double-valued state at the kernel's edges, so
+// registers and in the persistent state (bit i = row i; the host getters unpack them), so
 // "row i is all zero", "roll rows 0..n" and the phase-duration scans are a few integer instructions.  The
 // footstep table is produced row by row from registers and written once; the foot trajectory state is held in
 // statically indexed register arrays (the swing-feet list becomes a 4-bit mask).
@@ -104,22 +106,13 @@ __device__ __forceinline__ void rows_fill(Gm& m, int r0, int n, bool a, bool b, 
   if (c) m.c[2] |= f;
   if (d) m.c[3] |= f;
 }
-__device__ void gm_load(const PS& s, int item, int Ng, Gm& m) {
-  m.c[0] = m.c[1] = m.c[2] = m.c[3] = 0ull;
-#pragma unroll 4
-  for (int i = 0; i < Ng; i++) {
-    const double v0 = s(item + i * 4), v1 = s(item + i * 4 + 1), v2 = s(item + i * 4 + 2), v3 = s(item + i * 4 + 3);
-    m.c[0] |= (unsigned long long)(v0 != 0.0) << i;
-    m.c[1] |= (unsigned long long)(v1 != 0.0) << i;
-    m.c[2] |= (unsigned long long)(v2 != 0.0) << i;
-    m.c[3] |= (unsigned long long)(v3 != 0.0) << i;
-  }
-}
-__device__ void gm_store(const PS& s, int item, int Ng, const Gm& m) {
-#pragma unroll 4
-  for (int i = 0; i < Ng; i++)
+__device__ __forceinline__ void gm_load(const PS& s, int item, Gm& m) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) s(item + i * 4 + c) = ((m.c[c] >> i) & 1ull) ? 1.0 : 0.0;
+  for (int c = 0; c < 4; c++) m.c[c] = (unsigned long long)__double_as_longlong(s(item + c));
+}
+__device__ __forceinline__ void gm_store(const PS& s, int item, const Gm& m) {
+#pragma unroll
+  for (int c = 0; c < 4; c++) s(item + c) = __longlong_as_double((long long)m.c[c]);
 }
 
 // desired gait of one period (src/Gait.cpp:38-108); code 5 = walk (exists in the reference but is not reachable there)
@@ -367,9 +360,9 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
     for (int e = 0; e < 7; e++) s(L.qstatic + e) = 0.0;
     s(L.newphase) = 0.0; s(L.isstatic) = 0.0; s(L.remain) = 0.0; s(L.nfeet) = 0.0;
   } else if (uses_gait) {
-    gm_load(s, L.past, Ng, past);
-    gm_load(s, L.cur, Ng, cur);
-    gm_load(s, L.des, Ng, des);
+    gm_load(s, L.past, past);
+    gm_load(s, L.cur, cur);
+    gm_load(s, L.des, des);
     newphase = s(L.newphase);
     remain = s(L.remain);
   }
@@ -602,9 +595,9 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
   if (a.target && (a.mode & (kPlanFootsteps | kPlanOutputs)))
     for (int e = 0; e < 12; e++) a.target[(size_t)b * 12 + e] = have_otgt ? otgt[e] : s(L.otgt + e);
   if (gait_dirty) {
-    gm_store(s, L.past, Ng, past);
-    gm_store(s, L.cur, Ng, cur);
-    gm_store(s, L.des, Ng, des);
+    gm_store(s, L.past, past);
+    gm_store(s, L.cur, cur);
+    gm_store(s, L.des, des);
   }
   if (remain_dirty) s(L.remain) = remain;
 }

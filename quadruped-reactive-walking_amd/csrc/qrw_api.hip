@@ -539,9 +539,21 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
 extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double* h_out) {
   if (!h || !h_out || b < 0 || b >= h->cfg.batch || count < 1) return fail(-1, "qrw_planner_get_host: bad argument");
   const int off = qrw::planner_item_offset(h->cfg.N_gait, which);
-  if (off < 0 || off + count > qrw::planner_state_items(h->cfg.N_gait)) return fail(-1, "qrw_planner_get_host: bad item");
-  HIP_OK(hipDeviceSynchronize(), "sync");
   const size_t B = h->cfg.batch;
+  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (which >= 0 && which <= 2) {  // a gait matrix: stored as four 64-bit column masks, returned as N_gait x 4 doubles
+    if (count > h->cfg.N_gait * 4) return fail(-1, "qrw_planner_get_host: bad item");
+    double raw[4];
+    HIP_OK(hipMemcpy2D(raw, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), 4,
+                       hipMemcpyDeviceToHost), "D2H planner state");
+    for (int e = 0; e < count; e++) {
+      unsigned long long mask;
+      memcpy(&mask, &raw[e % 4], sizeof(mask));
+      h_out[e] = ((mask >> (e / 4)) & 1ull) ? 1.0 : 0.0;
+    }
+    return 0;
+  }
+  if (off < 0 || off + count > qrw::planner_state_items(h->cfg.N_gait)) return fail(-1, "qrw_planner_get_host: bad item");
   HIP_OK(hipMemcpy2D(h_out, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), count,
                      hipMemcpyDeviceToHost), "D2H planner state");
   return 0;
