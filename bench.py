@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--n-steps", type=int, default=16, help="MPC horizon")
     ap.add_argument("--gaits", type=str, default="trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary closed-loop figures (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16 cores)")
     args = ap.parse_args()
@@ -170,6 +171,7 @@ def main():
 
     if rank == 0 and world == 1:
         out["roofline"]["traffic"] = pmc_traffic_bytes()
+    if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
         out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
