@@ -6,9 +6,10 @@ sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, time
 import qrw_hip, synth
 names = ["factor", "rhs", "elim_g", "fwd_chain", "middle", "bwd_chain", "backsub+A+upd", "tail", "setup (assemble+Ruiz)", "check+rho"]
+NH = int(os.environ.get("QRW_PHASES_N", "16"))
 for B in (8, 4096):
-    sb = synth.SyntheticBatch(B, 16)
-    g = qrw_hip.Batch(B, 16)
+    sb = synth.SyntheticBatch(B, NH, N_gait=max(20, NH + 4), gaits=("trot",) if NH == 16 else ("walk", "trot", "bounding"))
+    g = qrw_hip.Batch(B, NH, N_gait=max(20, NH + 4), T_gait=0.02 * NH)
     lib = qrw_hip.load_library()
     lib.qrw_mpc_get_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     for s in range(3):
