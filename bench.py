@@ -283,7 +283,19 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
             t_mpc += b - a
             t_wbc += c - b
     tot = t_mpc + t_wbc
+    # BASELINE config 1: a single robot on a single thread (the reference's own deployment shape)
+    sb1 = synth.SyntheticBatch(1, N, N_gait=N_gait, gaits=gaits, n_seq=33)
+    m1, w1 = oracle.MPCBatch(1, 0.02, N, 0.02 * N, N_gait, fast=True), oracle.WbcBatch(1, 0.002, fast=True)
+    t1 = 0.0
+    for s in range(33):
+        d = sb1.step(s)
+        a = time.perf_counter()
+        r = m1.run(s, d["xref"], d["fsteps"], 1)
+        w1.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"], 1)
+        if s > 0:
+            t1 += time.perf_counter() - a
     return {"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
+            "single_instance_single_thread_steps_per_s": 32 / t1,
             "sample": "%d instances x %d control steps (after the set-up step), CPU restatement oracle/ "
                       "(OSQP-0.6-style, not OSQP itself), gcc -O3 -march=native, OpenMP one instance per thread" % (Bc, steps),
             "mpc_s": t_mpc, "wbc_s": t_wbc}
