@@ -24,6 +24,9 @@ ema = {}
 tot = {}
 for s in range(44):
     d = sb.step(s)
+    gait_now = (d["fsteps"].reshape(B, -1, 4, 3)[:, :N, :, 0] != 0)
+    sw0 = (gait_now[:, 0] != gait_prev[:, 0]).any(1).astype(float) if s > 0 else np.zeros(B)
+    gait_prev = gait_now
     g.mpc_solve_host(d["xref"], d["fsteps"], s)
     it = g.mpc_stats()["iters"].astype(float) + 9.0  # + setup/factor overhead in iteration units
     if prev is not None and s >= 3:
@@ -38,6 +41,9 @@ for s in range(44):
                 preds["period16"] = hist[-16]
                 preds["max(prev,period16)"] = np.maximum(hist[-1], hist[-16])
                 preds["mean(prev,period16)"] = 0.5 * (hist[-1] + hist[-16])
+            for al in (0.1, 0.2, 0.3, 0.5):
+                if 8 in ema:
+                    preds["ema8*(1+%.1f*sw0)" % al] = ema[8] * (1 + al * sw0)
             for a_ in (4, 8, 16):
                 if a_ in ema:
                     preds["ema%d" % a_] = ema[a_]
