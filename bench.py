@@ -161,7 +161,9 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": None,
                      "launch_ms": float(mpc_ms[-1]), "launch_ms_mean": float(mpc_ms.mean()),
                      "mean_admm_iters": float(ms["iters"].mean()), "max_admm_iters": int(ms["iters"].max()),
-                     "hbm_frac_algorithmic": (B * B_ALG / dur) / PEAK_HBM},
+                     "hbm_frac_algorithmic": (B * B_ALG / dur) / PEAK_HBM,
+                     "note": "compute roof: FP64 peak of gfx950 (vector = matrix = 78.6 TFLOP/s); the kernel is issue / "
+                             "latency bound and issues no MFMA (its sweeps run on the FP64 VALU with DPP, DESIGN.md 4.1)"},
         "kernels_ms": {"mpc_solve_kernel": float(mpc_ms.mean()), "wbc_kernel": float(wbc_ms.mean())},
         "solver": {"mpc_solved": n_ok, "mpc_instances": B, "wbc_mean_iters": float(ws["iters"].mean())},
         "mpc_solves_per_s": world * B * K / (mpc_ms.sum() * 1e-3) if world == 1 else None,
