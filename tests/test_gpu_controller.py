@@ -76,9 +76,22 @@ def test_glue_stages_match_oracle():
     assert [r.error_flag for r in refs] == [0, 1, 3, 3, 2, 0, 0]
 
 
+DEFAULT_CFG = dict(dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20, h_ref=0.2229)
+# other timings than the reference's yaml: 1 kHz WBC, MPC every 20th iteration, a 0.40 s gait on a 0.24 s horizon
+ALT_CFG = dict(dt_wbc=0.001, dt_mpc=0.02, k_mpc=20, T_gait=0.40, T_mpc=0.24, N_gait=26, h_ref=0.21)
+
+
+def test_closed_loop_other_timings(oracle_mod):
+    _closed_loop(oracle_mod, "sync", True, ALT_CFG, 70)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "separate"])
 @pytest.mark.parametrize("mode", ["sync", "async_lag0", "async_lag3"])
 def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
+    _closed_loop(oracle_mod, mode, fused, DEFAULT_CFG, 160 if (mode == "sync" and fused) else 45)
+
+
+def _closed_loop(oracle_mod, mode, fused, cfg, iters):
     """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
     made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state.  The
     asynchronous modes run the MPC on its own compute-unit-masked stream and adopt a result a fixed number of
@@ -87,23 +100,25 @@ def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
     import controller_oracle as co
     from Controller import Controller_batch
 
-    B, iters = 5, (160 if (mode == "sync" and fused) else 45)
+    B = 5
+    k_mpc, n_steps = cfg["k_mpc"], int(round(cfg["T_mpc"] / cfg["dt_mpc"]))
     lag = {"sync": 0, "async_lag0": 0, "async_lag3": 3}[mode]
     rng = np.random.default_rng(3)
-    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag, fused=fused)
-    glue = [co.ControllerGlue(Q_INIT, 0.2229, 0.002) for _ in range(B)]
-    plan = [oracle_mod.Planner() for _ in range(B)]
-    mpc = [oracle_mod.MPC(0.02, 16, 0.32, 20) for _ in range(B)]
-    wbc = [oracle_mod.WbcController(0.002) for _ in range(B)]
-    first = np.zeros((24, 16))
-    first[2, 0] = 0.2229
+    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag, fused=fused, **cfg)
+    glue = [co.ControllerGlue(Q_INIT, cfg["h_ref"], cfg["dt_wbc"]) for _ in range(B)]
+    plan = [oracle_mod.Planner(dt_mpc=cfg["dt_mpc"], dt_wbc=cfg["dt_wbc"], T_gait=cfg["T_gait"], T_mpc=cfg["T_mpc"],
+                               N_gait=cfg["N_gait"], k_mpc=k_mpc, h_ref=cfg["h_ref"]) for _ in range(B)]
+    mpc = [oracle_mod.MPC(cfg["dt_mpc"], n_steps, cfg["T_gait"], cfg["N_gait"]) for _ in range(B)]
+    wbc = [oracle_mod.WbcController(cfg["dt_wbc"]) for _ in range(B)]
+    first = np.zeros((24, n_steps))
+    first[2, 0] = cfg["h_ref"]
     first[12:, 0] = [0.0, 0.0, 8.0] * 4
     not_first = [False] * B
     issued = [[] for _ in range(B)]     # (iteration issued, result) per instance
     adopted = [None] * B
     vref = rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0])
     qf = np.zeros((B, 19))
-    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+    qf[:, 2], qf[:, 6], qf[:, 7:] = cfg["h_ref"], 1.0, Q_INIT
     vf = np.zeros((B, 18))
     worst = 0.0
     for k in range(iters):
@@ -120,7 +135,7 @@ def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
             oRh, oTh = g.update_state(vref[b], qf[b], vf[b], rpy[b])
             plan[b].step(k, g.q[:7, 0], g.h_v[:6, 0], g.v_ref[:6, 0], 0)
             xref, (fsteps, _, _), cgait = plan[b].xref(), plan[b].footsteps(), plan[b].gaits()[1]
-            if k % 10 == 0:
+            if k % k_mpc == 0:
                 mpc[b].run(k, xref, fsteps)
                 issued[b].append((k, mpc[b].get_latest_result().copy()))
             for k0, res_ in issued[b]:
