@@ -809,11 +809,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   int it, stt;
   qp_solve(io, st, j, valid, sol, it, stt);
   double dd[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) dd[i] = quad_sum(Aj[i][0] * sol[0] + Aj[i][1] * sol[1] + Aj[i][2] * sol[2]) + gamma[i];
   const double fw[3] = {sol[0] + fc[0], sol[1] + fc[1], sol[2] + fc[2]};
-  // second rnea with the base acceleration found by the QP (QP_WBC.py:110-116); only [6:] is used
-  const V3 alb = mk(dd[3], dd[4], dd[5]);
   double tau2[3], tff[3];
   {
     // recomputed (not carried across the solve): joint angles and quaternion are re-read so that the compiler cannot
@@ -835,6 +831,23 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       Rb2.r1 = mk(txy + twz, 1 - (txx + tzz), tyz - twx);
       Rb2.r2 = mk(txz - twy, tyz + twx, 1 - (txx + tyy));
     }
+    // A = Yinv X again (same arithmetic as above), then ddq_res = A f_res + gamma (QPWBC.cpp:285-289)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double acc = 0.0;
+      const V3 rt[3] = {Rb2.r0, Rb2.r1, Rb2.r2};
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const V3 col = mk(rt[t].x, rt[t].y, rt[t].z);
+        const V3 sc = cross(K2.pf, col);
+        const double xi = (i == 0) ? col.x : (i == 1) ? col.y : (i == 2) ? col.z : (i == 3) ? sc.x : (i == 4) ? sc.y : sc.z;
+        const double xv = stance ? xi : 0.0;
+        const double Ait = (1.0 / a.Y[i]) * xv;
+        acc = (t == 0) ? Ait * sol[0] : acc + Ait * sol[t];
+      }
+      dd[i] = quad_sum(acc) + gamma[i];
+    }
+    const V3 alb = mk(dd[3], dd[4], dd[5]);
     const V3 grav2 = mulT(Rb2, mk(0.0, 0.0, QRW_SOLO12_MODEL.gravity));
     const V3 ab02 = grav2 + cross(wb, vb);
     const V3 ab1 = ab02 + mk(dd[0], dd[1], dd[2]);
