@@ -4,7 +4,8 @@
 One "step" = one MPC::run + one wbc_controller.compute for every instance of the batch
 (ratio 1:1).  Default workload = BASELINE.json configs[2]: batch 4096, N = 16,
 trot, MPC + QPWBC + InvKin on one MI355X.  With --gpus N every rank owns its own 4096 instances
-(weak scaling) and the results are all-gathered (RCCL over xGMI) every step.
+(weak scaling).  Instances are independent, so the step has no collective; --gather-results adds the
+optional all-gather of the packed results (RCCL over xGMI) a central logger would want.
 
 Prints ONE JSON line (rank 0): metric/value/unit/... plus
   roofline     — dominant kernel (mpc_solve_kernel): algorithmic FP64 flops per launch (measured ADMM
@@ -45,6 +46,8 @@ def main():
     ap.add_argument("--n-steps", type=int, default=16, help="MPC horizon")
     ap.add_argument("--gaits", type=str, default="trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-results", action="store_true",
+                    help="N > 1: all-gather every rank's packed results each step (not part of the control path)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary closed-loop figures (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16 cores)")
@@ -93,7 +96,7 @@ def main():
     mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
     f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
     wbc_out = None
-    gather = ResultGatherer(B, 48, dev)
+    gather = ResultGatherer(B, 48, dev) if (world > 1 and args.gather_results) else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     ev_w = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     it_mpc, it_wbc = [], []
@@ -111,7 +114,7 @@ def main():
         wbc_out = eng.wbc_compute(q[s], dq[s], f_cmd, contacts[s], pg[s], vg[s], ag[s], out=wbc_out)
         if timed_idx is not None:
             ev_w[timed_idx][1].record()
-        if world > 1:
+        if gather is not None:
             gather.gather(pack_results(wbc_out["tau_ff"], wbc_out["f_with_delta"], wbc_out["qdes"], wbc_out["vdes"]))
 
     def barrier():
