@@ -44,7 +44,9 @@ def load(fast=False):
     if key in _lib_cache:
         return _lib_cache[key]
     path = os.path.join(_HERE, "libqrw_oracle_fast.so" if fast else "libqrw_oracle.so")
-    if not os.path.exists(path):
+    if not fast and os.environ.get("QRW_ORACLE_LIB"):  # e.g. the sanitizer build (make -C oracle san)
+        path = os.environ["QRW_ORACLE_LIB"]
+    elif not os.path.exists(path):
         build(fast)
     lib = C.CDLL(path)
     vp = C.c_void_p
