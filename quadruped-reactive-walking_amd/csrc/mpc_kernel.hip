@@ -43,7 +43,7 @@ struct alignas(16) MpcLdsT {
   double sX[(S + 2) * 12];   // step k at chain_pos(k); position N is a zero vector, N+1 padding for the idle step
   double sDump[(S / 2 + 2) * 12];  // sink for the sweeps' masked stores
   double sE[S * 12];     // step k <-> k+-1 exchange across wavefronts
-  double sW[S * kWSz];   // W_k = Gbar F^-1 Gbar' per step (factor phase)
+  double sW[S * kWSz];   // K_k^-1 = Omega_k - Gbar F^-1 Gbar' (6x6) per step (factor phase)
   double sOm[S * 12];    // omega_D per step (factor phase)
   double sDg[S * 12];    // c*w + sigma/Dx^2 per step (factor phase)
   double sA[kMatSz];     // Delta_{k-1}^-1
@@ -140,96 +140,90 @@ __device__ __forceinline__ double block_sum(double v, double* sRed, int wv, int 
 
 }  // namespace
 
-// Force block of the KKT system of one horizon step, per quad: F_k (12x12, rows 3j..3j+2 in lane j) is built and
-// inverted in place by Gauss-Jordan with quad DPP broadcasts, then Phi = F^-1 Gbar' (rows of lane j) and
-// W = Gbar Phi (6x6, summed over the quad).  omL / omA: omega_D of the linear / angular velocity rows of the step
-// (the values lanes 2 / 3 of the quad own), omS / omC: of this lane's force-enable / cone rows.
-__device__ __forceinline__ void force_block_factor(bool act, int j, const double (&Bang)[3][3], const double (&sfl)[3],
+// y = K^-1 s for the quad's 6x6 K^-1: lane j computes rows j and (j < 2 ? j + 4 : a duplicate) from its two rows Kr,
+// the six results are then broadcast inside the quad.  s must be the same in all four lanes.
+__device__ __forceinline__ void kinv_apply(const double (&Kr)[2][6], const double (&s)[6], double (&y)[6]) {
+  double ya = Kr[0][0] * s[0], yb = Kr[1][0] * s[0];
+#pragma unroll
+  for (int c = 1; c < 6; c++) { ya += Kr[0][c] * s[c]; yb += Kr[1][c] * s[c]; }
+  y[0] = quad_bcast<0>(ya); y[1] = quad_bcast<1>(ya); y[2] = quad_bcast<2>(ya); y[3] = quad_bcast<3>(ya);
+  y[4] = quad_bcast<0>(yb); y[5] = quad_bcast<1>(yb);
+}
+
+// Force block of the KKT system of one horizon step, per quad.  F_k = D + B' Omega B with D block-diagonal (one 3x3
+// per foot: cone rows, force-enable rows, cost and sigma) and B = [dt/m I; dt I^-1 skew(lever)] (6x12, the velocity rows
+// of the dynamics), so by the matrix inversion lemma everything the elimination needs comes from D_j^-1 (3x3, per lane)
+// and K^-1 = (Omega^-1 + B D^-1 B')^-1 (6x6, per step):
+//   Gbar F^-1 r        = -K^-1 B D^-1 r                       (Gbar = -Omega B; the term taken out of the state rhs)
+//   F^-1 (r - Gbar' d) = D^-1 r - D^-1 B' K^-1 (B D^-1 r - d) (force back-substitution)
+//   Omega - Gbar F^-1 Gbar' = K^-1                            (what the velocity block of the state system sees)
+// omL / omA: omega_D of the linear / angular velocity rows of the step (the values lanes 2 / 3 of the quad own),
+// omS / omC: of this lane's force-enable / cone rows.  Dinv: D_j^-1 as (00, 01, 02, 11, 12, 22); Kinv: K^-1 (every
+// lane of the quad holds the same copy).
+__device__ __forceinline__ void force_block_factor(bool act, const double (&Bang)[3][3], const double (&sfl)[3],
                                                    const double (&iDf)[3], const double (&omL)[3], const double (&omA)[3],
                                                    const double (&omS)[3], const double (&omC)[5], double cs, double wF,
-                                                   double sigma, double dtm, double mu, double (&Fi)[3][12],
-                                                   double (&Ph)[3][6], double (&W)[6][6]) {
-  // ---- force block F_k (rows of foot j), inverted inside the quad by Gauss-Jordan
-  double Ball[3][12];
+                                                   double sigma, double dtm, double mu, double (&Dinv)[6],
+                                                   double (&Kinv)[6][6]) {
+  // ---- D_j and its inverse (3x3 symmetric positive definite: adjugate / determinant)
+  const double s4 = omC[0] + omC[1] + omC[2] + omC[3];
+  const double d00 = omC[0] + omC[1] + (cs * wF + sigma * iDf[0] * iDf[0] + sfl[0] * sfl[0] * omS[0]);
+  const double d11 = omC[2] + omC[3] + (cs * wF + sigma * iDf[1] * iDf[1] + sfl[1] * sfl[1] * omS[1]);
+  const double d22 = mu * mu * s4 + omC[4] + (cs * wF + sigma * iDf[2] * iDf[2] + sfl[2] * sfl[2] * omS[2]);
+  const double d02 = -mu * (omC[0] - omC[1]), d12 = -mu * (omC[2] - omC[3]);  // d01 = 0
+  {
+    const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12, c02 = -d02 * d11;
+    const double c11 = d00 * d22 - d02 * d02, c12 = -d00 * d12, c22 = d00 * d11;
+    const double idet = 1.0 / (d00 * c00 + d02 * c02);
+    Dinv[0] = act ? c00 * idet : 1.0; Dinv[1] = act ? c01 * idet : 0.0; Dinv[2] = act ? c02 * idet : 0.0;
+    Dinv[3] = act ? c11 * idet : 1.0; Dinv[4] = act ? c12 * idet : 0.0; Dinv[5] = act ? c22 * idet : 1.0;
+  }
+  const double Ds[3][3] = {{Dinv[0], Dinv[1], Dinv[2]}, {Dinv[1], Dinv[3], Dinv[4]}, {Dinv[2], Dinv[4], Dinv[5]}};
+  // ---- K = Omega^-1 + sum over the feet of B_j D_j^-1 B_j'   (B_j = [dtm I; Bang_j])
+  double E[3][3];  // Bang D^-1
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      Ball[r][0 + t] = quad_bcast<0>(Bang[r][t]);
-      Ball[r][3 + t] = quad_bcast<1>(Bang[r][t]);
-      Ball[r][6 + t] = quad_bcast<2>(Bang[r][t]);
-      Ball[r][9 + t] = quad_bcast<3>(Bang[r][t]);
-    }
-  const double s4 = omC[0] + omC[1] + omC[2] + omC[3];
-  double cone[3][3] = {{omC[0] + omC[1], 0.0, -mu * (omC[0] - omC[1])},
-                       {0.0, omC[2] + omC[3], -mu * (omC[2] - omC[3])},
-                       {-mu * (omC[0] - omC[1]), -mu * (omC[2] - omC[3]), mu * mu * s4 + omC[4]}};
+    for (int c = 0; c < 3; c++) E[r][c] = Bang[r][0] * Ds[0][c] + Bang[r][1] * Ds[1][c] + Bang[r][2] * Ds[2][c];
+  double K[6][6];
 #pragma unroll
-  for (int t = 0; t < 3; t++)
+  for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int cb = 0; cb < 12; cb++) {
-      const int jb = cb / 3, tb = cb % 3;
-      double v = 0.0;
-#pragma unroll
-      for (int r = 0; r < 3; r++) v += omA[r] * Bang[r][t] * Ball[r][cb];
-      if (tb == t) v += dtm * dtm * omL[t];
-      if (jb == j) {
-        v += cone[t][tb];
-        if (tb == t) v += cs * wF + sigma * iDf[t] * iDf[t] + sfl[t] * sfl[t] * omS[t];
-      }
-      Fi[t][cb] = act ? v : ((jb == j && tb == t) ? 1.0 : 0.0);
+    for (int c = r; c < 3; c++) {
+      K[r][c] = quad_sum(act ? dtm * dtm * Ds[r][c] : 0.0);
+      K[3 + r][3 + c] = quad_sum(act ? E[r][0] * Bang[c][0] + E[r][1] * Bang[c][1] + E[r][2] * Bang[c][2] : 0.0);
     }
 #pragma unroll
-  for (int p = 0; p < 12; p++) {
-    const int jp = p / 3, tp = p % 3;
-    double prow[12];
+  for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int cb = 0; cb < 12; cb++) {
-      const double src = Fi[tp][cb];
-      prow[cb] = (jp == 0) ? quad_bcast<0>(src) : (jp == 1) ? quad_bcast<1>(src) : (jp == 2) ? quad_bcast<2>(src) : quad_bcast<3>(src);
+    for (int c = 0; c < 3; c++) K[c][3 + r] = quad_sum(act ? dtm * E[r][c] : 0.0);
+#pragma unroll
+  for (int c = 0; c < 3; c++) { K[c][c] += 1.0 / omL[c]; K[3 + c][3 + c] += 1.0 / omA[c]; }
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < r; c++) K[r][c] = K[c][r];
+  // ---- K^-1 by Gauss-Jordan (symmetric positive definite: no pivoting), the same in every lane of the quad
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+    const double d = 1.0 / K[p][p];
+    double prow[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) prow[c] = K[p][c] * d;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r == p) continue;
+      const double f = K[r][p];
+#pragma unroll
+      for (int c = 0; c < 6; c++) K[r][c] = (c == p) ? -f * d : K[r][c] - f * prow[c];
     }
-    const double d = 1.0 / prow[p];
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const bool isp = (j == jp) && (t == tp);
-      const double fcol = Fi[t][p];
-#pragma unroll
-      for (int cb = 0; cb < 12; cb++) {
-        double v;
-        if (cb == p) v = isp ? d : -fcol * d;
-        else v = isp ? prow[cb] * d : Fi[t][cb] - fcol * prow[cb] * d;
-        Fi[t][cb] = v;
-      }
-    }
+    for (int c = 0; c < 6; c++) K[p][c] = (c == p) ? d : prow[c];
   }
-  // Phi = F^-1 Gbar' (12x6), Gbar = -diag(omega_D[6:12]) B[6:12,:]
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
+  for (int r = 0; r < 6; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) Ph[t][c] = -omL[c] * dtm * (Fi[t][c] + Fi[t][3 + c] + Fi[t][6 + c] + Fi[t][9 + c]);
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      double v = 0.0;
-#pragma unroll
-      for (int cb = 0; cb < 12; cb++) v += Fi[t][cb] * Ball[r][cb];
-      Ph[t][3 + r] = -omA[r] * v;
-    }
-  }
-  // W = Gbar Phi (6x6, symmetric), reduced over the quad
-#pragma unroll
-  for (int c = 0; c < 6; c++)
-#pragma unroll
-    for (int c2 = c; c2 < 6; c2++) {
-      double v = 0.0;
-      if (c < 3) v = -omL[c] * dtm * Ph[c][c2];
-      else {
-#pragma unroll
-        for (int t = 0; t < 3; t++) v += -omA[c - 3] * Bang[c - 3][t] * Ph[t][c2];
-      }
-      v = quad_sum(act ? v : 0.0);
-      W[c][c2] = v;
-      W[c2][c] = v;
-    }
+    for (int c = 0; c < 6; c++) Kinv[r][c] = K[r][c];
 }
 
 // Twisted block LDL' over the states (see chain_sweep.h), in registers: DPP row 0 of wavefront 0 factorises chain A
@@ -266,13 +260,14 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
     if (worker) {
       // ---- Ttilde_kk, row i
       const double omki = L.sOm[kk * 12 + i], omni = nl * L.sOm[kn * 12 + i], omn6 = nl * L.sOm[kn * 12 + i6];
-      const double diag = (L.sDg[kk * 12 + i] + omki) + (omni + hi6 * (dt * dt * omn6));
+      // velocity rows: the dynamics rows' own omega is inside K^-1 (force_block_factor)
+      const double diag = L.sDg[kk * 12 + i] + lo6 * (omki + omni) + hi6 * (dt * dt * omn6);
 #pragma unroll
       for (int c = 0; c < 12; c++) {
         double v = (c == i) ? diag : 0.0;
         if (c >= 6) v = (c - 6 == i) ? dt * omni : v;          // (i, i+6), i < 6
         if (c < 6) v = (c + 6 == i) ? dt * omn6 : v;           // (i, i-6), i >= 6
-        if (c >= 6) v -= hi6 * (L.sW[kk * kWSz + i6 * 6 + (c - 6)] + nl * L.sW[kn * kWSz + i6 * 6 + (c - 6)]);
+        if (c >= 6) v += hi6 * (L.sW[kk * kWSz + i6 * 6 + (c - 6)] + nl * L.sW[kn * kWSz + i6 * 6 + (c - 6)]);
         m[c] = v;
       }
       // ---- Schur term of the step this chain eliminated just before: chain A  -N_kk C_kk', chain B  -Nt_kk C_{kk+1}
@@ -285,9 +280,9 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
         for (int c = 0; c < 6; c++) term[c] = -omS[c] * nn[c] - sA * (dt * omS[c]) * nn[c + 6];
 #pragma unroll
         for (int c = 6; c < 12; c++) {
-          double v = -omS[c] * nn[c] - sB * (dt * omS[c - 6]) * nn[c - 6];
+          double v = -sB * (dt * omS[c - 6]) * nn[c - 6];
 #pragma unroll
-          for (int mm = 0; mm < 6; mm++) v += WS[(c - 6) * 6 + mm] * nn[6 + mm];
+          for (int mm = 0; mm < 6; mm++) v -= WS[(c - 6) * 6 + mm] * nn[6 + mm];
           term[c] = v;
         }
         if (root) {  // the root couples to both chains: add the other chain's term
@@ -326,13 +321,13 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
       const double omk6 = L.sOm[kk * 12 + i6];
       const double* Wc = rowB ? &L.sW[kk * kWSz] : &L.sW[kn * kWSz];
       double nx[12], coef[6];
-      const double own = rowB ? omki : omni;
+      const double own = lo6 * (rowB ? omki : omni);
 #pragma unroll
       for (int c = 0; c < 12; c++) nx[c] = own * m[c];
-      // rows 6..11 of Delta^-1: the 6x6 velocity-block coupling (both chains; W is symmetric) and chain A's dt term
+      // rows 6..11 of Delta^-1: the 6x6 velocity-block coupling K^-1 (both chains; symmetric) and chain A's dt term
 #pragma unroll
       for (int mm = 0; mm < 6; mm++) {
-        double cf = -hi6 * Wc[i6 * 6 + mm];
+        double cf = hi6 * Wc[i6 * 6 + mm];
         if (mm == i) cf = sA * (dt * omni);  // i < 6 only: row i+6
         coef[mm] = cf;
       }
@@ -641,15 +636,15 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   lC4 = Ec[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
 
-  // factor data (per lane: 3 rows of F_k^-1, Delta_k^-1 and Phi_k = F_k^-1 Gbar_k')
-  double Fi[3][12], Di[3][12], Ph[3][6];
+  // factor data (per lane: D_j^-1 of the foot's force block, two rows of the step's K^-1, 3 rows of Delta_k^-1)
+  double Di[3][12], Dinv[6], Kr[2][6];
 #pragma unroll
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < 3; t++)
 #pragma unroll
-    for (int c = 0; c < 12; c++) Fi[t][c] = Di[t][c] = 0.0;
+    for (int c = 0; c < 12; c++) Di[t][c] = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; c++) Ph[t][c] = 0.0;
-  }
+  for (int c = 0; c < 6; c++) Dinv[c] = Kr[0][c] = Kr[1][c] = 0.0;
+  const int kr1 = (j < 2) ? j + 4 : j;  // lanes 0,1 of a quad also take rows 4,5 of K^-1 (lanes 2,3: a discarded duplicate)
 
   // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
   bool need_factor = true;
@@ -669,17 +664,17 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) { omD[t] = rho_eq * Ed[t] * Ed[t]; omS[t] = rho_eq * Es[t] * Es[t]; }
 #pragma unroll
       for (int c = 0; c < 5; c++) omC[c] = rho * Ec[c] * Ec[c];
-      double omL[3], omA[3], W[6][6];
+      double omL[3], omA[3], Kinv[6][6];
 #pragma unroll
       for (int t = 0; t < 3; t++) { omL[t] = quad_bcast<2>(omD[t]); omA[t] = quad_bcast<3>(omD[t]); }
-      force_block_factor(act, j, Bang, sfl, iDf, omL, omA, omS, omC, cs, wF, sigma, dtm, mu, Fi, Ph, W);
+      force_block_factor(act, Bang, sfl, iDf, omL, omA, omS, omC, cs, wF, sigma, dtm, mu, Dinv, Kinv);
       wg_sync();
       if (act) {
         if (j == 0) {
 #pragma unroll
           for (int c = 0; c < 6; c++)
 #pragma unroll
-            for (int c2 = 0; c2 < 6; c2++) L.sW[k * kWSz + c * 6 + c2] = W[c][c2];
+            for (int c2 = 0; c2 < 6; c2++) L.sW[k * kWSz + c * 6 + c2] = Kinv[c][c2];
         }
 #pragma unroll
         for (int t = 0; t < 3; t++) {
@@ -688,6 +683,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         }
       }
       wg_sync();
+#pragma unroll
+      for (int c = 0; c < 6; c++) { Kr[0][c] = L.sW[k * kWSz + j * 6 + c]; Kr[1][c] = L.sW[k * kWSz + kr1 * 6 + c]; }
       chain_factorize<T>(L, N, dt, tid, k, j, Di);
     PH(0);
     }  // need_factor
@@ -726,17 +723,22 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       }
     }
     PH(1);
-    // ---- 2. eliminate forces: r_X[v] -= g_k - g_{k+1}, g_k = Phi_k' r_f,k
+    // ---- 2. eliminate forces: r_X[v] -= g_k - g_{k+1}, g_k = Gbar F^-1 r_f,k = -K^-1 B D^-1 r_f,k
+    double tF[3], yK[6];  // D^-1 r_f and K^-1 B D^-1 r_f: kept for the back-substitution
     {
-      double g[6];
+      tF[0] = Dinv[0] * rF[0] + Dinv[1] * rF[1] + Dinv[2] * rF[2];
+      tF[1] = Dinv[1] * rF[0] + Dinv[3] * rF[1] + Dinv[4] * rF[2];
+      tF[2] = Dinv[2] * rF[0] + Dinv[4] * rF[1] + Dinv[5] * rF[2];
+      double sK[6];
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double v = Ph[0][c] * rF[0] + Ph[1][c] * rF[1] + Ph[2][c] * rF[2];
-        g[c] = quad_sum(act ? v : 0.0);
+      for (int t = 0; t < 3; t++) {
+        sK[t] = dtm * quad_sum(act ? tF[t] : 0.0);
+        sK[3 + t] = quad_sum(act ? Bang[t][0] * tF[0] + Bang[t][1] * tF[1] + Bang[t][2] * tF[2] : 0.0);
       }
+      kinv_apply(Kr, sK, yK);
       double gsV[3], gnV[3], gdum[3];
 #pragma unroll
-      for (int t = 0; t < 3; t++) gsV[t] = (j == 3) ? g[3 + t] : g[t];
+      for (int t = 0; t < 3; t++) gsV[t] = -((j == 3) ? yK[3 + t] : yK[t]);
       nb_next<NW>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
 #pragma unroll
       for (int t = 0; t < 3; t++) rX[t] += mGN * gnV[t] - mG * gsV[t];
@@ -789,21 +791,18 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         xpi[t] = xp[3 * j + t];
         xpi6[t] = xp[3 * ((j + 2) & 3) + t];
       }
-      double rFa[12];
+      // f = F^-1 (r_f - Gbar' dV) = D^-1 r_f - D^-1 B' (K^-1 B D^-1 r_f - K^-1 dV)
+      double zK[6], wB[3];
+      kinv_apply(Kr, dV, zK);
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        rFa[0 + t] = quad_bcast<0>(rF[t]); rFa[3 + t] = quad_bcast<1>(rF[t]);
-        rFa[6 + t] = quad_bcast<2>(rF[t]); rFa[9 + t] = quad_bcast<3>(rF[t]);
-      }
+      for (int c = 0; c < 6; c++) zK[c] = yK[c] - zK[c];
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        double v = 0.0;
+      for (int t = 0; t < 3; t++) wB[t] = dtm * zK[t] + Bang[0][t] * zK[3] + Bang[1][t] * zK[4] + Bang[2][t] * zK[5];
+      fh[0] = tF[0] - (Dinv[0] * wB[0] + Dinv[1] * wB[1] + Dinv[2] * wB[2]);
+      fh[1] = tF[1] - (Dinv[1] * wB[0] + Dinv[3] * wB[1] + Dinv[4] * wB[2]);
+      fh[2] = tF[2] - (Dinv[2] * wB[0] + Dinv[4] * wB[1] + Dinv[5] * wB[2]);
 #pragma unroll
-        for (int c = 0; c < 12; c++) v += Fi[t][c] * rFa[c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) v -= Ph[t][c] * dV[c];
-        fh[t] = act ? v : 0.0;
-      }
+      for (int t = 0; t < 3; t++) fh[t] = act ? fh[t] : 0.0;
     }
     double zDt[3], zSt[3], zCt[5];
     {
