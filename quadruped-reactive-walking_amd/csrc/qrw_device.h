@@ -19,8 +19,9 @@ constexpr double kMaxScaling = 1e4;
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // every lane has a source lane under these controls: no tied "old" value, so the result needs no copy of v first
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // broadcast lane J (0..3) of each quad to the whole quad
