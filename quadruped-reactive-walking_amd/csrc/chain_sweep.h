@@ -61,10 +61,129 @@ struct ChainOp {
 };
 typedef double qrw_d2 __attribute__((ext_vector_type(2)));
 
+// lanes 0..31 <-> lanes 32..63 of the same register (gfx950 v_permlane32_swap with both operands the same VGPR)
+__device__ __forceinline__ double swap_halves(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %0\n\tv_permlane32_swap_b32 %1, %1" : "+v"(lo), "+v"(hi));
+  return __hiloint2double(hi, lo);
+}
+
+// Paired sweeps (compile-time N with an even number of steps per chain): an LDS read moves 64 lanes whatever EXEC says
+// (scripts/ubench/exec_rate.hip), and the chains only fill lanes 0..31.  So one set of reads fetches the operands of
+// TWO consecutive steps -- lanes 0..31 those of step 2p+1, lanes 32..63 those of step 2p+2 -- and the running vector
+// changes halves between the steps (two v_permlane32_swap): half the LDS instructions and half the LDS bandwidth of
+// the one-step form, the same 12 FMAs per step in the same order (bit-identical results).
+template <int NC>
+__device__ __forceinline__ void chain_forward_paired(const double* sN, double* sX, double* sDump, int lane) {
+  constexpr int N = NC, m = N >> 1, LA = m, LB = N - 1 - m, NP = LA / 2;
+  static_assert(LA % 2 == 0 && LB == LA - 1, "paired sweeps need an even chain length");
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const int h = lane >> 5;
+  const bool rw = (lane & 16) != 0;
+  const bool own = (lane & 15) < 12;
+  const double* pm = sN + (rw ? m * kSlot : 0) + h * kSlot + i;  // pair p: + 2p*kSlot + c*kCol
+  double* px = sX + (rw ? (m + 1) * 12 : 0) + i;                 // step t: + t*12
+  const double* pr = px + h * 12;                                // rhs of pair p: + (2p+1)*12
+  double* dump = sDump + i;
+  double* ps_lo = (own && h == 0) ? px : dump;           // odd steps (computed in lanes 0..31), both chains
+  double* ps_hi = (own && h == 1) ? px : dump;           // even steps (lanes 32..63), both chains
+  double* ps_loA = (own && h == 0 && !rw) ? px : dump;   // step LB (odd): chain A only
+  double x = px[0], pB = 0.0;
+  ChainOp b0, b1;
+  auto fetch = [&](ChainOp& b, int p) {
+    const double* q = pm + 2 * p * kSlot;
+#pragma unroll
+    for (int c = 0; c < 12; c++) b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    b.r = pr[(2 * p + 1) * 12];
+  };
+  auto pair = [&](const ChainOp& b, int p) {
+    const int t1 = 2 * p + 1, t2 = t1 + 1;
+    x = dpp_step12(b.r, x, b.m);  // step t1, valid in lanes 0..31
+    if (t1 == LB) pB = x;
+    (t1 < LB ? ps_lo : ps_loA)[t1 * 12] = x;
+    x = swap_halves(x);
+    x = dpp_step12(b.r, x, b.m);  // step t2, valid in lanes 32..63
+    if (t2 < LA) {
+      ps_hi[t2 * 12] = x;
+      x = swap_halves(x);
+    }
+  };
+  fetch(b0, 0);
+#pragma unroll
+  for (int p = 0; p < NP; p += 2) {
+    if (p + 1 < NP) fetch(b1, p + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    pair(b0, p);
+    if (p + 1 < NP) {
+      if (p + 2 < NP) fetch(b0, p + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      pair(b1, p + 1);
+    }
+  }
+  // root: chain A's last step sits in lanes 32..43, chain B's contribution (step LB, odd) in lanes 16..27
+  x += shfl(pB, (lane & 15) + 16);
+  if (lane >= 32 && lane < 44) sX[m * 12 + i] = x;
+}
+template <int NC>
+__device__ __forceinline__ void chain_backward_paired(const double* sN, double* sX, double* sDump, int lane) {
+  constexpr int N = NC, m = N >> 1, LA = m, LB = N - 1 - m, NP = LA / 2;
+  static_assert(LA % 2 == 0 && LB == LA - 1, "paired sweeps need an even chain length");
+  asm volatile("" : "+v"(lane));
+  const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
+  const int h = lane >> 5;
+  const bool rw = (lane & 16) != 0;
+  const bool own = (lane & 15) < 12;
+  const double* pm = sN + ((rw ? (N - 1) : m) - LA - h) * kSlot + i * kCol;  // pair p: + (LA-2p-1)*kSlot + c
+  double* px = sX + ((rw ? N : m) - LA) * 12 + i;                             // step t: + (LA-t)*12
+  const double* pr = px - h * 12;                                             // pair p: + (LA-2p-1)*12
+  double* dump = sDump + i;
+  double* ps_lo = (own && h == 0) ? px : dump;           // odd steps, both chains
+  double* ps_hi = (own && h == 1) ? px : dump;           // even steps t <= LB, both chains
+  double* ps_hiA = (own && h == 1 && !rw) ? px : dump;   // step LA (even): chain A only
+  double x = sX[m * 12 + i];
+  ChainOp b0, b1;
+  auto fetch = [&](ChainOp& b, int p) {
+    const qrw_d2* q = reinterpret_cast<const qrw_d2*>(pm + (LA - 2 * p - 1) * kSlot);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const qrw_d2 v = q[c];
+      b.m[2 * c] = v.x;
+      b.m[2 * c + 1] = v.y;
+    }
+    b.r = pr[(LA - 2 * p - 1) * 12];
+  };
+  auto pair = [&](const ChainOp& b, int p) {
+    const int t1 = 2 * p + 1, t2 = t1 + 1;
+    x = dpp_step12(b.r, x, b.m);  // step t1, lanes 0..31
+    ps_lo[(LA - t1) * 12] = x;
+    x = swap_halves(x);
+    x = dpp_step12(b.r, x, b.m);  // step t2, lanes 32..63
+    (t2 <= LB ? ps_hi : ps_hiA)[(LA - t2) * 12] = x;
+    if (t2 < LA) x = swap_halves(x);
+  };
+  fetch(b0, 0);
+#pragma unroll
+  for (int p = 0; p < NP; p += 2) {
+    if (p + 1 < NP) fetch(b1, p + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    pair(b0, p);
+    if (p + 1 < NP) {
+      if (p + 2 < NP) fetch(b0, p + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      pair(b1, p + 1);
+    }
+  }
+}
+
 // sDump: (NC/2 + 2) * 12 doubles of LDS that absorb the stores of lanes / steps that must not write (cheaper than
 // switching EXEC around every store: a lone wavefront pays full issue time for each scalar instruction).
 template <int NC>
 __device__ __forceinline__ void chain_forward(const double* sN, double* sX, double* sDump, int Nrt, int lane) {
+  if constexpr (NC > 0 && (NC / 2) % 2 == 0) {
+    chain_forward_paired<NC>(sN, sX, sDump, lane);
+    return;
+  }
   const int N = NC ? NC : Nrt;
   const int m = N >> 1, LA = m, LB = N - 1 - m;
   if (LA == 0) return;
@@ -116,6 +235,10 @@ __device__ __forceinline__ void chain_forward(const double* sN, double* sX, doub
 // Transposed reads of the same slots (row i of M' is contiguous: 6 ds_read_b128).
 template <int NC>
 __device__ __forceinline__ void chain_backward(const double* sN, double* sX, double* sDump, int Nrt, int lane) {
+  if constexpr (NC > 0 && (NC / 2) % 2 == 0) {
+    chain_backward_paired<NC>(sN, sX, sDump, lane);
+    return;
+  }
   const int N = NC ? NC : Nrt;
   const int m = N >> 1, LA = m, LB = N - 1 - m;
   if (LA == 0) return;
