@@ -637,11 +637,14 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   lC4 = Ec[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
 
   // factor data (per lane: D_j^-1 of the foot's force block, two rows of the step's K^-1, 3 rows of Delta_k^-1)
-  double Di[3][12], Dinv[6], Kr[2][6];
+  // Delta^-1 rows are read once per iteration: pinned in accumulation registers (AccD) so that the register allocator
+  // keeps the architectural ones for values the loop touches more often
+  double Dinv[6], Kr[2][6];
+  AccD Di[3][12];
 #pragma unroll
   for (int t = 0; t < 3; t++)
 #pragma unroll
-    for (int c = 0; c < 12; c++) Di[t][c] = 0.0;
+    for (int c = 0; c < 12; c++) Di[t][c].set(0.0);
 #pragma unroll
   for (int c = 0; c < 6; c++) Dinv[c] = Kr[0][c] = Kr[1][c] = 0.0;
   const int kr1 = (j < 2) ? j + 4 : j;  // lanes 0,1 of a quad also take rows 4,5 of K^-1 (lanes 2,3: a discarded duplicate)
@@ -685,7 +688,18 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       wg_sync();
 #pragma unroll
       for (int c = 0; c < 6; c++) { Kr[0][c] = L.sW[k * kWSz + j * 6 + c]; Kr[1][c] = L.sW[k * kWSz + kr1 * 6 + c]; }
-      chain_factorize<T>(L, N, dt, tid, k, j, Di);
+      {
+        double DiV[3][12];
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+          for (int c = 0; c < 12; c++) DiV[t][c] = Di[t][c].get();
+        chain_factorize<T>(L, N, dt, tid, k, j, DiV);
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+          for (int c = 0; c < 12; c++) Di[t][c].set(DiV[t][c]);
+      }
     PH(0);
     }  // need_factor
 
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) {
         double s_ = 0.0;
 #pragma unroll
-        for (int c = 0; c < 12; c++) s_ += Di[t][c] * u[c];
+        for (int c = 0; c < 12; c++) s_ += Di[t][c].get() * u[c];
         v[t] = s_;
       }
       wg_sync();

@@ -60,6 +60,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// A double parked in two accumulation registers (gfx950: 256 AGPRs beside the 256 architectural VGPRs; VALU
+// instructions cannot read them, one v_accvgpr_read per half brings the value back).
+struct AccD {
+  int lo, hi;
+  __device__ __forceinline__ void set(double v) {
+    const int l = __double2loint(v), h = __double2hiint(v);
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(l));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(h));
+  }
+  __device__ __forceinline__ double get() const {
+    int l, h;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+    return __hiloint2double(h, l);
+  }
+};
+
 // OSQP limit_scaling()
 __device__ __forceinline__ double limit_scaling(double d) {
   d = d < kMinScaling ? 1.0 : d;
