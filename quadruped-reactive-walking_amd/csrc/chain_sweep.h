@@ -61,7 +61,8 @@ struct ChainOp {
 };
 typedef double qrw_d2 __attribute__((ext_vector_type(2)));
 
-// lanes 0..31 <-> lanes 32..63 of the same register (gfx950 v_permlane32_swap with both operands the same VGPR)
+// lanes 0..31 <-> lanes 32..63 of the same register (gfx950 v_permlane32_swap with both operands the same VGPR).
+// The s_nop is required: without wait states after the VALU write of v the exchange reads stale data (measured).
 __device__ __forceinline__ double swap_halves(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %0\n\tv_permlane32_swap_b32 %1, %1" : "+v"(lo), "+v"(hi));
@@ -77,7 +78,6 @@ template <int NC>
 __device__ __forceinline__ void chain_forward_paired(const double* sN, double* sX, double* sDump, int lane) {
   constexpr int N = NC, m = N >> 1, LA = m, LB = N - 1 - m, NP = LA / 2;
   static_assert(LA % 2 == 0 && LB == LA - 1, "paired sweeps need an even chain length");
-  asm volatile("" : "+v"(lane));
   const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
   const int h = lane >> 5;
   const bool rw = (lane & 16) != 0;
@@ -129,7 +129,6 @@ template <int NC>
 __device__ __forceinline__ void chain_backward_paired(const double* sN, double* sX, double* sDump, int lane) {
   constexpr int N = NC, m = N >> 1, LA = m, LB = N - 1 - m, NP = LA / 2;
   static_assert(LA % 2 == 0 && LB == LA - 1, "paired sweeps need an even chain length");
-  asm volatile("" : "+v"(lane));
   const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
   const int h = lane >> 5;
   const bool rw = (lane & 16) != 0;

@@ -774,9 +774,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int c = 0; c < 12; c++) u[c] = L.sX[kx * 12 + c];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        double s_ = 0.0;
+        double s_ = 0.0, dr[12];
+        AccD::get12(Di[t], dr);
 #pragma unroll
-        for (int c = 0; c < 12; c++) s_ += Di[t][c].get() * u[c];
+        for (int c = 0; c < 12; c++) s_ += dr[c] * u[c];
         v[t] = s_;
       }
       wg_sync();

@@ -69,6 +69,24 @@ struct AccD {
     asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(l));
     asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(h));
   }
+  // twelve at once: one asm statement, so the compiler pads for the asm-to-VALU hazard once instead of per value
+  static __device__ __forceinline__ void get12(const AccD (&a)[12], double (&v)[12]) {
+    int l[12], h[12];
+    asm("v_accvgpr_read_b32 %0, %24\n\tv_accvgpr_read_b32 %1, %25\n\tv_accvgpr_read_b32 %2, %26\n\tv_accvgpr_read_b32 %3, %27\n\t"
+        "v_accvgpr_read_b32 %4, %28\n\tv_accvgpr_read_b32 %5, %29\n\tv_accvgpr_read_b32 %6, %30\n\tv_accvgpr_read_b32 %7, %31\n\t"
+        "v_accvgpr_read_b32 %8, %32\n\tv_accvgpr_read_b32 %9, %33\n\tv_accvgpr_read_b32 %10, %34\n\tv_accvgpr_read_b32 %11, %35\n\t"
+        "v_accvgpr_read_b32 %12, %36\n\tv_accvgpr_read_b32 %13, %37\n\tv_accvgpr_read_b32 %14, %38\n\tv_accvgpr_read_b32 %15, %39\n\t"
+        "v_accvgpr_read_b32 %16, %40\n\tv_accvgpr_read_b32 %17, %41\n\tv_accvgpr_read_b32 %18, %42\n\tv_accvgpr_read_b32 %19, %43\n\t"
+        "v_accvgpr_read_b32 %20, %44\n\tv_accvgpr_read_b32 %21, %45\n\tv_accvgpr_read_b32 %22, %46\n\tv_accvgpr_read_b32 %23, %47"
+        : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3]), "=&v"(l[4]), "=&v"(h[4]),
+          "=&v"(l[5]), "=&v"(h[5]), "=&v"(l[6]), "=&v"(h[6]), "=&v"(l[7]), "=&v"(h[7]), "=&v"(l[8]), "=&v"(h[8]), "=&v"(l[9]), "=&v"(h[9]),
+          "=&v"(l[10]), "=&v"(h[10]), "=&v"(l[11]), "=&v"(h[11])
+        : "a"(a[0].lo), "a"(a[0].hi), "a"(a[1].lo), "a"(a[1].hi), "a"(a[2].lo), "a"(a[2].hi), "a"(a[3].lo), "a"(a[3].hi), "a"(a[4].lo),
+          "a"(a[4].hi), "a"(a[5].lo), "a"(a[5].hi), "a"(a[6].lo), "a"(a[6].hi), "a"(a[7].lo), "a"(a[7].hi), "a"(a[8].lo), "a"(a[8].hi),
+          "a"(a[9].lo), "a"(a[9].hi), "a"(a[10].lo), "a"(a[10].hi), "a"(a[11].lo), "a"(a[11].hi));
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = __hiloint2double(h[c], l[c]);
+  }
   __device__ __forceinline__ double get() const {
     int l, h;
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
