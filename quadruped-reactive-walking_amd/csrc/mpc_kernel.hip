@@ -628,13 +628,31 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   const double cinv = 1.0 / cs;
   double iDx[3], iDf[3];
-  double uD[3], lC4;
+#pragma unroll
+  for (int t = 0; t < 3; t++) { iDx[t] = 1.0 / Dx0[t]; iDf[t] = 1.0 / Df0[t]; }
+  // The loop carries OSQP's scaled iterates in a form that needs no scaling products per iteration (same recursion):
+  //   xh   = D xbar                         (the unscaled primal iterate)
+  //   eta  = E ybar                         for every row;  theta = eta - zeta_u for the dynamics rows
+  //   zeta = rho_row E zbar                 for the cone rows (the dynamics rows sit on their bound zeta_u = Omega u after
+  //                                         the first projection, the force-enable rows on 0)
+  // with Omega = rho_row E^2, so that A'(rho z - y) = A_hat' (zeta - eta), zeta+ = clip(alpha Omega A_hat x~ +
+  // (1-alpha) zeta + eta, Omega l, Omega u) and eta+ = (alpha Omega A_hat x~ + (1-alpha) zeta + eta) - zeta+.
+  double xhX[3], xhF[3], thD[3], etS[3], zeC[5], etC[5];
+#pragma unroll
+  for (int t = 0; t < 3; t++) { xhX[t] = Dx0[t] * xX[t]; xhF[t] = Df0[t] * xF[t]; etS[t] = Es[t] * yS[t]; }
+#pragma unroll
+  for (int c = 0; c < 5; c++) etC[c] = Ec[c] * yC[c];
+  // per-lane constants of the current rho (set with every factorisation)
+  double aOD[3], kD[3], zeU[3], aOS[3], aOC[5], sDx2[3], sDf2[3], lz4 = 0.0;
 #pragma unroll
   for (int t = 0; t < 3; t++) {
-    iDx[t] = 1.0 / Dx0[t]; iDf[t] = 1.0 / Df0[t];
-    uD[t] = Ed[t] * uD0[t];
+    aOD[t] = kD[t] = zeU[t] = aOS[t] = thD[t] = 0.0;
+    sDx2[t] = sigma * iDx[t] * iDx[t]; sDf2[t] = sigma * iDf[t] * iDf[t];
   }
-  lC4 = Ec[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
+#pragma unroll
+  for (int c = 0; c < 5; c++) aOC[c] = zeC[c] = 0.0;
+  double wD[3];  // zeta - eta of the dynamics rows, as the next right-hand side needs it (first iteration: warm start)
+  double rho_used = 1.0;  // rho of the current factorisation and loop constants
 
   // factor data (per lane: D_j^-1 of the foot's force block, two rows of the step's K^-1, 3 rows of Delta_k^-1)
   // Delta^-1 rows are read once per iteration: pinned in accumulation registers (AccD) so that the register allocator
@@ -650,11 +668,29 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const int kr1 = (j < 2) ? j + 4 : j;  // lanes 0,1 of a quad also take rows 4,5 of K^-1 (lanes 2,3: a discarded duplicate)
 
   // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
+#ifdef QRW_DEBUG_SUMS
+  double dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   bool need_factor = true;
   int iter = 0, status = kStatusUnsolved, rho_updates = 0;
   double pri_res = 0.0, dua_res = 0.0, last_np = 0.0, last_nd = 0.0;
   const int max_iter = 4000;
   rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+  {  // loop variables from the warm start (OSQP's scaled x, z, y of the previous solve, used as they are)
+    rho_used = rho;
+    const double rho_eq0 = kRhoEqOverIneq * rho;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      zeU[t] = (rho_eq0 * Ed[t] * Ed[t]) * uD0[t];
+      const double eta = Ed[t] * yD[t], ze0 = rho_eq0 * Ed[t] * zD[t];
+      // first iteration: zbar is the warm start, not yet the bound: the right-hand side takes zeta0 - eta0, and eta is
+      // shifted so that the relaxed update sees (1-alpha) zeta0 where later iterations see (1-alpha) zeta_u
+      wD[t] = act ? ze0 - eta : 0.0;
+      thD[t] = (eta + (1.0 - alpha) * (ze0 - zeU[t])) - zeU[t];
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) zeC[c] = rho * Ec[c] * zC[c];
+  }
 
   PH(8);
   for (iter = 1; iter <= max_iter; iter++) {
@@ -667,6 +703,27 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) { omD[t] = rho_eq * Ed[t] * Ed[t]; omS[t] = rho_eq * Es[t] * Es[t]; }
 #pragma unroll
       for (int c = 0; c < 5; c++) omC[c] = rho * Ec[c] * Ec[c];
+      {  // loop constants of this rho; eta is independent of rho, zeta scales with it (no-ops on the first pass)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const double zu_new = omD[t] * uD0[t];
+          const double shift = zu_new - zeU[t];
+          thD[t] -= shift;
+          wD[t] = act ? wD[t] + shift : 0.0;
+          zeU[t] = zu_new;
+          aOD[t] = alpha * omD[t];
+          kD[t] = alpha * zu_new;
+          aOS[t] = alpha * omS[t] * sfl[t];
+        }
+        const double rs = rho / rho_used;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          zeC[c] *= rs;
+          aOC[c] = alpha * omC[c];
+        }
+        rho_used = rho;
+        lz4 = omC[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
+      }
       double omL[3], omA[3], Kinv[6][6];
 #pragma unroll
       for (int t = 0; t < 3; t++) { omL[t] = quad_bcast<2>(omD[t]); omA[t] = quad_bcast<3>(omD[t]); }
@@ -701,19 +758,27 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           for (int c = 0; c < 12; c++) Di[t][c].set(DiV[t][c]);
       }
     PH(0);
+#ifdef QRW_DEBUG_SUMS
+      if (iter == 1) {
+        double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0, q9 = 0;
+        for (int t = 0; t < 3; t++) {
+          double dr[12]; AccD::get12(Di[t], dr);
+          for (int c = 0; c < 12; c++) q0 += dr[c] * (1 + c + 12 * t);
+          q3 += thD[t] * (t + 1); q4 += wD[t] * (t + 1); q6 += aOD[t] + 2 * kD[t] + 3 * zeU[t]; q7 += aOS[t]; q9 += sDx2[t] + 2 * sDf2[t];
+        }
+        for (int c = 0; c < 6; c++) { q1 += Kr[0][c] * (c + 1) + Kr[1][c] * (c + 7); q2 += Dinv[c] * (c + 1); }
+        for (int c = 0; c < 5; c++) { q5 += zeC[c] * (c + 1); q7 += aOC[c] * (c + 2); }
+        const double w = 1.0 + 0.01 * lane;
+        dbg[0] = wave_sum(q0 * w); dbg[1] = wave_sum(q1 * w); dbg[2] = wave_sum(q2 * w); dbg[3] = wave_sum(q3 * w); dbg[4] = wave_sum(q4 * w);
+        dbg[5] = wave_sum(q5 * w); dbg[6] = wave_sum(q6 * w); dbg[7] = wave_sum(q7 * w); dbg[8] = lz4 + rho_used; dbg[9] = wave_sum(q9 * w);
+      }
+#endif
     }  // need_factor
 
-    const double rho_eq = kRhoEqOverIneq * rho;
-    const double rho_inv = 1.0 / rho, rho_eq_inv = 1.0 / rho_eq;
     // ---- 1. hatted right-hand side r = sigma x / D + A' E (rho z - y)      (OSQP compute_rhs + KKT reduction)
-    double wD[3], wSv[3], wC[5];
+    double wC[5];
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      wD[t] = act ? Ed[t] * (rho_eq * (zD[t] - rho_eq_inv * yD[t])) : 0.0;
-      wSv[t] = Es[t] * (rho_eq * (0.0 - rho_eq_inv * yS[t]));
-    }
-#pragma unroll
-    for (int c = 0; c < 5; c++) wC[c] = Ec[c] * (rho * (zC[c] - rho_inv * yC[c]));
+    for (int c = 0; c < 5; c++) wC[c] = zeC[c] - etC[c];
     double rX[3], rF[3], coneT[3];
     cone_apply_t(wC, mu, coneT);
     double wnV[3], wn6V[3];
@@ -722,7 +787,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     for (int t = 0; t < 3; t++) {
       const double wn = wnV[t], wn6 = wn6V[t];
       const double v = mN * wn + mN6 * wn6 - wD[t];
-      rX[t] = sigma * xX[t] * iDx[t] + v;
+      rX[t] = sDx2[t] * xhX[t] + v;
     }
     {
       double wL[3], wA[3];
@@ -730,10 +795,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) { wL[t] = quad_bcast<2>(wD[t]); wA[t] = quad_bcast<3>(wD[t]); }
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        double v = dtm * wL[t] + sfl[t] * wSv[t] + coneT[t];
+        double v = dtm * wL[t] - sfl[t] * etS[t] + coneT[t];
 #pragma unroll
         for (int r = 0; r < 3; r++) v += Bang[r][t] * wA[r];
-        rF[t] = sigma * xF[t] * iDf[t] + v;
+        rF[t] = sDf2[t] * xhF[t] + v;
       }
     }
     PH(1);
@@ -819,46 +884,32 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
       for (int t = 0; t < 3; t++) fh[t] = act ? fh[t] : 0.0;
     }
-    double zDt[3], zSt[3], zCt[5];
     {
-      double pl[3], pa[3];
+      double pl[3], pa[3], cv[5];
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         pl[t] = quad_sum(fh[t]);
         pa[t] = quad_sum(Bang[t][0] * fh[0] + Bang[t][1] * fh[1] + Bang[t][2] * fh[2]);
       }
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const double v = mP * xpi[t] + mP6 * xpi6[t] + cL * pl[t] + cA * pa[t] - xh[t];
-        zDt[t] = Ed[t] * v;
-        zSt[t] = Es[t] * sfl[t] * fh[t];
-      }
-      double cv[5];
       cone_apply(fh, mu, cv);
 #pragma unroll
-      for (int c = 0; c < 5; c++) zCt[c] = Ec[c] * cv[c];
-    }
+      for (int t = 0; t < 3; t++) {
+        const double v = mP * xpi[t] + mP6 * xpi6[t] + cL * pl[t] + cA * pa[t] - xh[t];  // dynamics row of A_hat x~
+        xhX[t] = alpha * xh[t] + (1.0 - alpha) * xhX[t];
+        xhF[t] = alpha * fh[t] + (1.0 - alpha) * xhF[t];
+        // equality rows: z is projected onto [u,u], so zeta stays zeta_u and only theta = eta - zeta_u moves
+        thD[t] = fma(aOD[t], v, thD[t]) - kD[t];
+        wD[t] = act ? -thD[t] : 0.0;
+        etS[t] = fma(aOS[t], fh[t], etS[t]);  // force-enable rows: z is identically 0 (l = u = 0)
+      }
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-      xX[t] = alpha * (xh[t] * iDx[t]) + (1.0 - alpha) * xX[t];
-      xF[t] = alpha * (fh[t] * iDf[t]) + (1.0 - alpha) * xF[t];
-      // equality rows: z is projected onto [u,u]
-      const double zr = alpha * zDt[t] + (1.0 - alpha) * zD[t];
-      double zn = zr + rho_eq_inv * yD[t];
-      zn = fmin(fmax(zn, uD[t]), uD[t]);
-      yD[t] += rho_eq * (zr - zn);
-      zD[t] = zn;
-      const double zs = alpha * zSt[t];  // z_S is identically 0 (l = u = 0)
-      yS[t] += rho_eq * (zs - 0.0);
-    }
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-      const double zr = alpha * zCt[c] + (1.0 - alpha) * zC[c];
-      double zn = zr + rho_inv * yC[c];
-      if (c == 4) zn = fmax(zn, lC4);
-      zn = fmin(zn, 0.0);
-      yC[c] += rho * (zr - zn);
-      zC[c] = zn;
+      for (int c = 0; c < 5; c++) {
+        const double s_ = fma(aOC[c], cv[c], (1.0 - alpha) * zeC[c]) + etC[c];
+        double zn = (c == 4) ? fmax(s_, lz4) : s_;
+        zn = fmin(zn, 0.0);
+        etC[c] = s_ - zn;
+        zeC[c] = zn;
+      }
     }
 
     PH(6);
@@ -871,9 +922,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) { Dx[t] = 1.0 / iDx[t]; Df[t] = 1.0 / iDf[t]; iEd[t] = 1.0 / Ed[t]; iEs[t] = 1.0 / Es[t]; }
 #pragma unroll
       for (int c = 0; c < 5; c++) iEc[c] = 1.0 / Ec[c];
-      double xhX[3], xhF[3];
+      // OSQP's scaled z of the rows that can move (the dynamics rows sit on their bound, the force-enable rows on 0)
+      double zD[3], zC[5];
 #pragma unroll
-      for (int t = 0; t < 3; t++) { xhX[t] = Dx[t] * xX[t]; xhF[t] = Df[t] * xF[t]; }
+      for (int t = 0; t < 3; t++) zD[t] = Ed[t] * uD0[t];
+#pragma unroll
+      for (int c = 0; c < 5; c++) zC[c] = zeC[c] * (1.0 / (rho_used * Ec[c]));
       wg_sync();
       if (act) {
 #pragma unroll
@@ -930,9 +984,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       if (need_dual) {
         double eD[3], eS[3], eC[5], cT[3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) { eD[t] = act ? Ed[t] * yD[t] : 0.0; eS[t] = Es[t] * yS[t]; }
+        for (int t = 0; t < 3; t++) { eD[t] = act ? thD[t] + zeU[t] : 0.0; eS[t] = etS[t]; }
 #pragma unroll
-        for (int c = 0; c < 5; c++) eC[c] = Ec[c] * yC[c];
+        for (int c = 0; c < 5; c++) eC[c] = etC[c];
         cone_apply_t(eC, mu, cT);
         double eL[3], eA[3];
 #pragma unroll
@@ -998,6 +1052,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #ifdef QRW_PROFILE_PHASES
   if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
 #endif
+#ifdef QRW_DEBUG_SUMS
+  if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = dbg[i];
+#endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved) {
     // max_iter reached (4000 % 25 == 0: the residuals of the last iterate were just computed): OSQP re-checks with
@@ -1013,12 +1070,22 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const int i = 3 * j + t;
-      const double sx = has_sol ? (1.0 / iDx[t]) * xX[t] + xr[i * (N + 1) + k + 1] : nan("");
-      const double sf = has_sol ? (1.0 / iDf[t]) * xF[t] : nan("");
+      const double sx = has_sol ? xhX[t] + xr[i * (N + 1) + k + 1] : nan("");
+      const double sf = has_sol ? xhF[t] : nan("");
       a.out[(size_t)b * 24 * N + i * N + k] = sx;           // retrieve_result, MPC.cpp:573
       a.out[(size_t)b * 24 * N + (12 + i) * N + k] = sf;    // MPC.cpp:574
     }
   }
+  // back to OSQP's scaled iterates for the persistent state
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    xX[t] = xhX[t] * iDx[t]; xF[t] = xhF[t] * iDf[t];
+    zD[t] = Ed[t] * uD0[t];
+    yD[t] = (thD[t] + zeU[t]) * (1.0 / Ed[t]);
+    yS[t] = etS[t] * (1.0 / Es[t]);
+  }
+#pragma unroll
+  for (int c = 0; c < 5; c++) { zC[c] = zeC[c] * (1.0 / (rho_used * Ec[c])); yC[c] = etC[c] * (1.0 / Ec[c]); }
   if (!has_sol) {  // store_solution(): cold start after a failed solve
 #pragma unroll
     for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = 0.0;

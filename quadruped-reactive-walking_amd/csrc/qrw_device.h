@@ -62,6 +62,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // A double parked in two accumulation registers (gfx950: 256 AGPRs beside the 256 architectural VGPRs; VALU
 // instructions cannot read them, one v_accvgpr_read per half brings the value back).
+#ifdef QRW_NO_ACCD  // diagnostic: plain registers, allocation left to the compiler
+struct AccD {
+  double v_;
+  __device__ __forceinline__ void set(double v) { v_ = v; }
+  __device__ __forceinline__ double get() const { return v_; }
+  static __device__ __forceinline__ void get12(const AccD (&a)[12], double (&v)[12]) {
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = a[c].v_;
+  }
+};
+#else
 struct AccD {
   int lo, hi;
   __device__ __forceinline__ void set(double v) {
@@ -72,7 +83,17 @@ struct AccD {
   // twelve at once: one asm statement, so the compiler pads for the asm-to-VALU hazard once instead of per value
   static __device__ __forceinline__ void get12(const AccD (&a)[12], double (&v)[12]) {
     int l[12], h[12];
-    asm("v_accvgpr_read_b32 %0, %24\n\tv_accvgpr_read_b32 %1, %25\n\tv_accvgpr_read_b32 %2, %26\n\tv_accvgpr_read_b32 %3, %27\n\t"
+#ifdef QRW_ACCD_GET1
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = a[c].get();
+    return;
+#endif
+#ifdef QRW_ACCD_VOL
+    asm volatile(
+#else
+    asm(
+#endif
+        "v_accvgpr_read_b32 %0, %24\n\tv_accvgpr_read_b32 %1, %25\n\tv_accvgpr_read_b32 %2, %26\n\tv_accvgpr_read_b32 %3, %27\n\t"
         "v_accvgpr_read_b32 %4, %28\n\tv_accvgpr_read_b32 %5, %29\n\tv_accvgpr_read_b32 %6, %30\n\tv_accvgpr_read_b32 %7, %31\n\t"
         "v_accvgpr_read_b32 %8, %32\n\tv_accvgpr_read_b32 %9, %33\n\tv_accvgpr_read_b32 %10, %34\n\tv_accvgpr_read_b32 %11, %35\n\t"
         "v_accvgpr_read_b32 %12, %36\n\tv_accvgpr_read_b32 %13, %37\n\tv_accvgpr_read_b32 %14, %38\n\tv_accvgpr_read_b32 %15, %39\n\t"
@@ -94,6 +115,8 @@ struct AccD {
     return __hiloint2double(h, l);
   }
 };
+
+#endif
 
 // OSQP limit_scaling()
 __device__ __forceinline__ double limit_scaling(double d) {
