@@ -668,9 +668,6 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const int kr1 = (j < 2) ? j + 4 : j;  // lanes 0,1 of a quad also take rows 4,5 of K^-1 (lanes 2,3: a discarded duplicate)
 
   // =========================== C/D. factor + ADMM loop (OSQP osqp_solve) ===========================
-#ifdef QRW_DEBUG_SUMS
-  double dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   bool need_factor = true;
   int iter = 0, status = kStatusUnsolved, rho_updates = 0;
   double pri_res = 0.0, dua_res = 0.0, last_np = 0.0, last_nd = 0.0;
@@ -758,21 +755,6 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           for (int c = 0; c < 12; c++) Di[t][c].set(DiV[t][c]);
       }
     PH(0);
-#ifdef QRW_DEBUG_SUMS
-      if (iter == 1) {
-        double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0, q9 = 0;
-        for (int t = 0; t < 3; t++) {
-          double dr[12]; AccD::get12(Di[t], dr);
-          for (int c = 0; c < 12; c++) q0 += dr[c] * (1 + c + 12 * t);
-          q3 += thD[t] * (t + 1); q4 += wD[t] * (t + 1); q6 += aOD[t] + 2 * kD[t] + 3 * zeU[t]; q7 += aOS[t]; q9 += sDx2[t] + 2 * sDf2[t];
-        }
-        for (int c = 0; c < 6; c++) { q1 += Kr[0][c] * (c + 1) + Kr[1][c] * (c + 7); q2 += Dinv[c] * (c + 1); }
-        for (int c = 0; c < 5; c++) { q5 += zeC[c] * (c + 1); q7 += aOC[c] * (c + 2); }
-        const double w = 1.0 + 0.01 * lane;
-        dbg[0] = wave_sum(q0 * w); dbg[1] = wave_sum(q1 * w); dbg[2] = wave_sum(q2 * w); dbg[3] = wave_sum(q3 * w); dbg[4] = wave_sum(q4 * w);
-        dbg[5] = wave_sum(q5 * w); dbg[6] = wave_sum(q6 * w); dbg[7] = wave_sum(q7 * w); dbg[8] = lz4 + rho_used; dbg[9] = wave_sum(q9 * w);
-      }
-#endif
     }  // need_factor
 
     // ---- 1. hatted right-hand side r = sigma x / D + A' E (rho z - y)      (OSQP compute_rhs + KKT reduction)
@@ -1051,9 +1033,6 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   PH(7);
 #ifdef QRW_PROFILE_PHASES
   if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
-#endif
-#ifdef QRW_DEBUG_SUMS
-  if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = dbg[i];
 #endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved) {
