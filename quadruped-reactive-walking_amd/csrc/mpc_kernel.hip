@@ -55,7 +55,10 @@ struct alignas(16) MpcLdsT {
 __device__ __forceinline__ void wg_sync() { __syncthreads(); }
 #ifdef QRW_PROFILE_PHASES
 #define PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0,0,0,0,0,0,0,0,0,0};
-#define PH(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } while (0)
+#ifndef QRW_PH_MASK
+#define QRW_PH_MASK 0x3FF
+#endif
+#define PH(i) do { if ((QRW_PH_MASK >> (i)) & 1) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } } while (0)
 #elif defined(QRW_MARK_PHASES)  // markers in the ISA listing (scripts/phase_mix.py counts instructions per phase)
 #define PH_DECL
 #define PH(i) asm volatile("; QRW_PHASE " #i)
