@@ -901,6 +901,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     // ---- 5. termination / adaptive rho (OSQP update_info, check_termination, adapt_rho)
     const bool check = (iter % 25 == 0);
     if (check) {
+      PH(6);  // (diagnostic builds) everything up to here is the update phase; the check itself is accounted to slot 7
       // inverse scalings are only needed here (every 25 iterations): recomputed instead of held in registers
       double Dx[3], Df[3], iEd[3], iEs[3], iEc[5];
 #pragma unroll
@@ -1031,6 +1032,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           need_factor = true;
         }
       }
+      PH(7);
     }
   }
   PH(7);

@@ -5,7 +5,8 @@ os.environ["QRW_HIP_LIB"] = os.path.join(ROOT, "build", "libqrw_hip_prof.so")
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, time
 import qrw_hip, synth
-names = ["factor", "rhs", "elim_g", "fwd_chain", "middle", "bwd_chain", "backsub+A+upd", "tail", "setup (assemble+Ruiz)", "check+rho"]
+names = ["factor", "rhs", "elim_g", "fwd_chain", "middle", "bwd_chain", "backsub+A+upd", "check block (every 25th)", "setup (assemble+Ruiz)",
+         "end of update + loop edge"]
 NH = int(os.environ.get("QRW_PHASES_N", "16"))
 for B in (8, 4096):
     sb = synth.SyntheticBatch(B, NH, N_gait=max(20, NH + 4), gaits=("trot",) if NH == 16 else ("walk", "trot", "bounding"))
@@ -21,4 +22,4 @@ for B in (8, 4096):
         print("B=%d step %d: wall %.2f ms, mean iters %.0f, cycles/iter (mean over instances) %.0f" % (B, s, (t1 - t0) * 1e3, it.mean(), (tot / it).mean()))
         per = prof / it[:, None]
         for i, n in enumerate(names):
-            print("   %-14s %8.0f cyc/iter  (%.1f%%)" % (n, per[:, i].mean(), 100 * prof[:, i].sum() / tot.sum()))
+            print("   %-26s %8.0f cyc/iter  (%.1f%%)" % (n, per[:, i].mean(), 100 * prof[:, i].sum() / tot.sum()))
