@@ -86,9 +86,11 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
   double* px = sX + (rw ? (m + 1) * 12 : 0) + i;                 // step t: + t*12
   const double* pr = px + h * 12;                                // rhs of pair p: + (2p+1)*12
   double* dump = sDump + i;
-  double* ps_lo = (own && h == 0) ? px : dump;           // odd steps (computed in lanes 0..31), both chains
-  double* ps_hi = (own && h == 1) ? px : dump;           // even steps (lanes 32..63), both chains
-  double* ps_loA = (own && h == 0 && !rw) ? px : dump;   // step LB (odd): chain A only
+  // a step's result is stored AFTER it has changed halves (the exchange can then work in place: nothing else still
+  // needs the unexchanged value), i.e. by the lanes of the half the step was NOT computed in
+  double* ps_odd = (own && h == 1) ? px : dump;           // odd steps (computed in lanes 0..31), both chains
+  double* ps_even = (own && h == 0) ? px : dump;          // even steps (computed in lanes 32..63), both chains
+  double* ps_oddA = (own && h == 1 && !rw) ? px : dump;   // step LB (odd): chain A only
   double x = px[0], pB = 0.0;
   ChainOp b0, b1;
   auto fetch = [&](ChainOp& b, int p) {
@@ -99,14 +101,14 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
   };
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, x, b.m);  // step t1, valid in lanes 0..31
+    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
+    x = swap_halves(x);           // now in lanes 32..63
     if (t1 == LB) pB = x;
-    (t1 < LB ? ps_lo : ps_loA)[t1 * 12] = x;
-    x = swap_halves(x);
-    x = dpp_step12(b.r, x, b.m);  // step t2, valid in lanes 32..63
+    (t1 < LB ? ps_odd : ps_oddA)[t1 * 12] = x;
+    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
     if (t2 < LA) {
-      ps_hi[t2 * 12] = x;
-      x = swap_halves(x);
+      x = swap_halves(x);         // now in lanes 0..31
+      ps_even[t2 * 12] = x;
     }
   };
   fetch(b0, 0);
@@ -121,8 +123,8 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
       pair(b1, p + 1);
     }
   }
-  // root: chain A's last step sits in lanes 32..43, chain B's contribution (step LB, odd) in lanes 16..27
-  x += shfl(pB, (lane & 15) + 16);
+  // root: chain A's last step sits in lanes 32..43, chain B's contribution (step LB, odd, exchanged) in lanes 48..59
+  x += shfl(pB, (lane & 15) + 48);
   if (lane >= 32 && lane < 44) sX[m * 12 + i] = x;
 }
 template <int NC>
@@ -137,9 +139,9 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   double* px = sX + ((rw ? N : m) - LA) * 12 + i;                             // step t: + (LA-t)*12
   const double* pr = px - h * 12;                                             // pair p: + (LA-2p-1)*12
   double* dump = sDump + i;
-  double* ps_lo = (own && h == 0) ? px : dump;           // odd steps, both chains
-  double* ps_hi = (own && h == 1) ? px : dump;           // even steps t <= LB, both chains
-  double* ps_hiA = (own && h == 1 && !rw) ? px : dump;   // step LA (even): chain A only
+  double* ps_odd = (own && h == 1) ? px : dump;           // odd steps (stored after the exchange), both chains
+  double* ps_even = (own && h == 0) ? px : dump;          // even steps t < LA (stored after the exchange), both chains
+  double* ps_lastA = (own && h == 1 && !rw) ? px : dump;  // step LA (even, not exchanged): chain A only
   double x = sX[m * 12 + i];
   ChainOp b0, b1;
   auto fetch = [&](ChainOp& b, int p) {
@@ -154,12 +156,16 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   };
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, x, b.m);  // step t1, lanes 0..31
-    ps_lo[(LA - t1) * 12] = x;
+    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
     x = swap_halves(x);
-    x = dpp_step12(b.r, x, b.m);  // step t2, lanes 32..63
-    (t2 <= LB ? ps_hi : ps_hiA)[(LA - t2) * 12] = x;
-    if (t2 < LA) x = swap_halves(x);
+    ps_odd[(LA - t1) * 12] = x;
+    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
+    if (t2 < LA) {
+      x = swap_halves(x);
+      ps_even[(LA - t2) * 12] = x;  // t2 < LA = LB + 1: both chains
+    } else {
+      ps_lastA[(LA - t2) * 12] = x;
+    }
   };
   fetch(b0, 0);
 #pragma unroll
