@@ -12,12 +12,14 @@
 // (k,3j..3j+2), force-enable rows (k,3j..3j+2) and the 5 friction-cone rows of foot j at step k:
 // 6 of the 24N variables and 11 of the 44N constraints per lane — all ADMM vectors live in
 // registers.  The KKT solve (P + sigma I + A' R A) x = r is done by block elimination:
-//   1. forces f_k are eliminated per step inside each quad (12x12 inverse held as 3 rows per lane),
+//   1. forces f_k are eliminated per step inside each quad through the matrix inversion lemma (a 3x3 inverse per foot
+//      and a 6x6 inverse per step, force_block_factor),
 //   2. the remaining block-tridiagonal system in the states (12x12 blocks, N steps) is solved by a twisted
 //      (two-ended) block LDL' recursion; factorisation and the two sequential sweeps run on the FP64 VALU with DPP
 //      row broadcasts (v_fmac_f64_dpp row_newbcast: lane i of a 16-lane row holds vector entry i and matrix row i;
 //      chain_sweep.h), both chains in one instruction stream,
 //   3. forces are back-substituted inside each quad.
+// The loop carries OSQP's scaled iterates in unscaled ("hatted") form, see the comment at the loop variables.
 // LDS holds the N-1 chain matrices (column-major 12x12) and one 12N exchange vector.
 #include <hip/hip_runtime.h>
 #include <math.h>
