@@ -296,7 +296,7 @@ __device__ __forceinline__ void gj_pivot(double (&m)[12], int i) {
   double piv = 0.0;
   const double one = 1.0;
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(piv) : "v"(m[P]), "v"(one), "n"(P));
-  const double d = 1.0 / piv;
+  const double d = fast_rcp(piv);
   const double f = (i == P) ? (d - 1.0) : (-m[P] * d);
   asm("s_nop 1\n\t" QRW_GJ_FM(0) QRW_GJ_FM(1) QRW_GJ_FM(2) QRW_GJ_FM(3) QRW_GJ_FM(4) QRW_GJ_FM(5) QRW_GJ_FM(6) QRW_GJ_FM(7)
       QRW_GJ_FM(8) QRW_GJ_FM(9) QRW_GJ_FM(10) QRW_GJ_FM(11)

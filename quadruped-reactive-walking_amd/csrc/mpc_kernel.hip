@@ -179,7 +179,7 @@ __device__ __forceinline__ void force_block_factor(bool act, const double (&Bang
   {
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12, c02 = -d02 * d11;
     const double c11 = d00 * d22 - d02 * d02, c12 = -d00 * d12, c22 = d00 * d11;
-    const double idet = 1.0 / (d00 * c00 + d02 * c02);
+    const double idet = fast_rcp(d00 * c00 + d02 * c02);
     Dinv[0] = act ? c00 * idet : 1.0; Dinv[1] = act ? c01 * idet : 0.0; Dinv[2] = act ? c02 * idet : 0.0;
     Dinv[3] = act ? c11 * idet : 1.0; Dinv[4] = act ? c12 * idet : 0.0; Dinv[5] = act ? c22 * idet : 1.0;
   }
@@ -203,7 +203,7 @@ __device__ __forceinline__ void force_block_factor(bool act, const double (&Bang
 #pragma unroll
     for (int c = 0; c < 3; c++) K[c][3 + r] = quad_sum(act ? dtm * E[r][c] : 0.0);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { K[c][c] += 1.0 / omL[c]; K[3 + c][3 + c] += 1.0 / omA[c]; }
+  for (int c = 0; c < 3; c++) { K[c][c] += fast_rcp(omL[c]); K[3 + c][3 + c] += fast_rcp(omA[c]); }
 #pragma unroll
   for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -211,7 +211,7 @@ __device__ __forceinline__ void force_block_factor(bool act, const double (&Bang
   // ---- K^-1 by Gauss-Jordan (symmetric positive definite: no pivoting), the same in every lane of the quad
 #pragma unroll
   for (int p = 0; p < 6; p++) {
-    const double d = 1.0 / K[p][p];
+    const double d = fast_rcp(K[p][p]);
     double prow[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) prow[c] = K[p][c] * d;
@@ -695,12 +695,31 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
     for (int c = 0; c < 5; c++) zeC[c] = rho * Ec[c] * zC[c];
   }
+  // values only the factorisation, the termination check and the exit read: parked in accumulation registers, so that
+  // they do not compete with the loop's own values for the architectural ones
+  AccD pEd[3], pEs[3], pEc[5], pIDx[3], pIDf[3], pUD0[3], pWX[3], pCs;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    pEd[t].set(Ed[t]); pEs[t].set(Es[t]); pIDx[t].set(iDx[t]); pIDf[t].set(iDf[t]); pUD0[t].set(uD0[t]); pWX[t].set(wX[t]);
+  }
+#pragma unroll
+  for (int c = 0; c < 5; c++) pEc[c].set(Ec[c]);
+  pCs.set(cs);
+#define QRW_UNPARK()                                                                                        \
+  double Ed[3], Es[3], Ec[5], iDx[3], iDf[3], uD0[3], wX[3];                                                \
+  _Pragma("unroll") for (int t = 0; t < 3; t++) {                                                           \
+    Ed[t] = pEd[t].get(); Es[t] = pEs[t].get(); iDx[t] = pIDx[t].get(); iDf[t] = pIDf[t].get();              \
+    uD0[t] = pUD0[t].get(); wX[t] = pWX[t].get();                                                           \
+  }                                                                                                         \
+  _Pragma("unroll") for (int c = 0; c < 5; c++) Ec[c] = pEc[c].get();                                       \
+  const double cs = pCs.get();
 
   PH(8);
   for (iter = 1; iter <= max_iter; iter++) {
     PH(9);
     if (need_factor) {
       need_factor = false;
+      QRW_UNPARK()
       const double rho_eq = kRhoEqOverIneq * rho;
       double omD[3], omS[3], omC[5];
 #pragma unroll
@@ -906,18 +925,20 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     const bool check = (iter % 25 == 0);
     if (check) {
       PH(6);  // (diagnostic builds) everything up to here is the update phase; the check itself is accounted to slot 7
+      QRW_UNPARK()
+      const double cinv = fast_rcp(cs);
       // inverse scalings are only needed here (every 25 iterations): recomputed instead of held in registers
       double Dx[3], Df[3], iEd[3], iEs[3], iEc[5];
 #pragma unroll
-      for (int t = 0; t < 3; t++) { Dx[t] = 1.0 / iDx[t]; Df[t] = 1.0 / iDf[t]; iEd[t] = 1.0 / Ed[t]; iEs[t] = 1.0 / Es[t]; }
+      for (int t = 0; t < 3; t++) { Dx[t] = fast_rcp(iDx[t]); Df[t] = fast_rcp(iDf[t]); iEd[t] = fast_rcp(Ed[t]); iEs[t] = fast_rcp(Es[t]); }
 #pragma unroll
-      for (int c = 0; c < 5; c++) iEc[c] = 1.0 / Ec[c];
+      for (int c = 0; c < 5; c++) iEc[c] = fast_rcp(Ec[c]);
       // OSQP's scaled z of the rows that can move (the dynamics rows sit on their bound, the force-enable rows on 0)
       double zD[3], zC[5];
 #pragma unroll
       for (int t = 0; t < 3; t++) zD[t] = Ed[t] * uD0[t];
 #pragma unroll
-      for (int c = 0; c < 5; c++) zC[c] = zeC[c] * (1.0 / (rho_used * Ec[c]));
+      for (int c = 0; c < 5; c++) zC[c] = zeC[c] * (iEc[c] * fast_rcp(rho_used));
       wg_sync();
       if (act) {
 #pragma unroll
@@ -1053,6 +1074,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 
   // =========================== E. results + persistent state ===========================
+  {
+  QRW_UNPARK()
   const bool has_sol = (status != kStatusNonCvx);
   if (act) {
 #pragma unroll
@@ -1101,6 +1124,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     a.dua[b] = dua_res;
     a.rho_updates[b] = rho_updates;
   }
+  }
+#undef QRW_UNPARK
 #undef ST
 }
 

@@ -118,6 +118,16 @@ struct AccD {
 
 #endif
 
+// Reciprocal from the hardware estimate and two Newton steps (<= 1 ulp for the well-scaled positive values it is used
+// on: pivots, scalings, rho) -- a quarter of the instructions of the IEEE division sequence.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
 // OSQP limit_scaling()
 __device__ __forceinline__ double limit_scaling(double d) {
   d = d < kMinScaling ? 1.0 : d;
