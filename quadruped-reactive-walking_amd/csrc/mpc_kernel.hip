@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 #pragma unroll
   for (int c = 0; c < 5; c++) aOC[c] = zeC[c] = 0.0;
+  const double aVel = (j >= 2) ? alpha : 0.0;
   double wD[3];  // zeta - eta of the dynamics rows, as the next right-hand side needs it (first iteration: warm start)
   double rho_used = 1.0;  // rho of the current factorisation and loop constants
 
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           thD[t] -= shift;
           wD[t] = act ? wD[t] + shift : 0.0;
           zeU[t] = zu_new;
-          aOD[t] = alpha * omD[t];
+          aOD[t] = (j >= 2) ? 0.0 : alpha * omD[t];  // velocity rows take alpha dK instead (see the update)
           kD[t] = alpha * zu_new;
           aOS[t] = alpha * omS[t] * sfl[t];
         }
@@ -866,8 +867,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     wg_sync();
     PH(5);
     // ---- 4. back-substitute forces, apply A, update the iterates
-    const double cL = (j == 2) ? dtm : 0.0, cA = (j == 3) ? 1.0 : 0.0;
-    double dV[6], fh[3], xh[3], xpi[3], xpi6[3];
+    double dV[6], fh[3], xh[3], xpi[3], xpi6[3], dK[6];
     {
       const double* xc = &L.sX[kx * 12];
       const double* xp = &L.sX[kpx * 12];
@@ -880,12 +880,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         xpi6[t] = xp[3 * ((j + 2) & 3) + t];
       }
       // f = F^-1 (r_f - Gbar' dV) = D^-1 r_f - D^-1 B' (K^-1 B D^-1 r_f - K^-1 dV)
-      double zK[6], wB[3];
-      kinv_apply(Kr, dV, zK);
+      double wB[3];
+      kinv_apply(Kr, dV, dK);
 #pragma unroll
-      for (int c = 0; c < 6; c++) zK[c] = yK[c] - zK[c];
+      for (int c = 0; c < 6; c++) dK[c] = yK[c] - dK[c];
 #pragma unroll
-      for (int t = 0; t < 3; t++) wB[t] = dtm * zK[t] + Bang[0][t] * zK[3] + Bang[1][t] * zK[4] + Bang[2][t] * zK[5];
+      for (int t = 0; t < 3; t++) wB[t] = dtm * dK[t] + Bang[0][t] * dK[3] + Bang[1][t] * dK[4] + Bang[2][t] * dK[5];
       fh[0] = tF[0] - (Dinv[0] * wB[0] + Dinv[1] * wB[1] + Dinv[2] * wB[2]);
       fh[1] = tF[1] - (Dinv[1] * wB[0] + Dinv[3] * wB[1] + Dinv[4] * wB[2]);
       fh[2] = tF[2] - (Dinv[2] * wB[0] + Dinv[4] * wB[1] + Dinv[5] * wB[2]);
@@ -893,20 +893,19 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       for (int t = 0; t < 3; t++) fh[t] = act ? fh[t] : 0.0;
     }
     {
-      double pl[3], pa[3], cv[5];
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        pl[t] = quad_sum(fh[t]);
-        pa[t] = quad_sum(Bang[t][0] * fh[0] + Bang[t][1] * fh[1] + Bang[t][2] * fh[2]);
-      }
+      double cv[5];
       cone_apply(fh, mu, cv);
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        const double v = mP * xpi[t] + mP6 * xpi6[t] + cL * pl[t] + cA * pa[t] - xh[t];  // dynamics row of A_hat x~
+        // dynamics row of A_hat x~.  Position rows (feet 0,1): x_{k-1} + dt v_{k-1} - x_k.  Velocity rows (feet 2,3):
+        // v_{k-1} + B f - v_k, and with f from the elimination B f = dV + Omega^-1 (K^-1 B D^-1 r_f - K^-1 dV), so the
+        // row is Omega^-1 dK and alpha Omega (row) = alpha dK: no sum over the feet is needed (aOD is 0 on these lanes)
+        const double v = mP * xpi[t] + mP6 * xpi6[t] - xh[t];
+        const double dsel = (j == 3) ? dK[3 + t] : dK[t];
         xhX[t] = alpha * xh[t] + (1.0 - alpha) * xhX[t];
         xhF[t] = alpha * fh[t] + (1.0 - alpha) * xhF[t];
         // equality rows: z is projected onto [u,u], so zeta stays zeta_u and only theta = eta - zeta_u moves
-        thD[t] = fma(aOD[t], v, thD[t]) - kD[t];
+        thD[t] = fma(aVel, dsel, fma(aOD[t], v, thD[t])) - kD[t];
         wD[t] = act ? -thD[t] : 0.0;
         etS[t] = fma(aOS[t], fh[t], etS[t]);  // force-enable rows: z is identically 0 (l = u = 0)
       }
