@@ -83,17 +83,7 @@ struct AccD {
   // twelve at once: one asm statement, so the compiler pads for the asm-to-VALU hazard once instead of per value
   static __device__ __forceinline__ void get12(const AccD (&a)[12], double (&v)[12]) {
     int l[12], h[12];
-#ifdef QRW_ACCD_GET1
-#pragma unroll
-    for (int c = 0; c < 12; c++) v[c] = a[c].get();
-    return;
-#endif
-#ifdef QRW_ACCD_VOL
-    asm volatile(
-#else
-    asm(
-#endif
-        "v_accvgpr_read_b32 %0, %24\n\tv_accvgpr_read_b32 %1, %25\n\tv_accvgpr_read_b32 %2, %26\n\tv_accvgpr_read_b32 %3, %27\n\t"
+    asm("v_accvgpr_read_b32 %0, %24\n\tv_accvgpr_read_b32 %1, %25\n\tv_accvgpr_read_b32 %2, %26\n\tv_accvgpr_read_b32 %3, %27\n\t"
         "v_accvgpr_read_b32 %4, %28\n\tv_accvgpr_read_b32 %5, %29\n\tv_accvgpr_read_b32 %6, %30\n\tv_accvgpr_read_b32 %7, %31\n\t"
         "v_accvgpr_read_b32 %8, %32\n\tv_accvgpr_read_b32 %9, %33\n\tv_accvgpr_read_b32 %10, %34\n\tv_accvgpr_read_b32 %11, %35\n\t"
         "v_accvgpr_read_b32 %12, %36\n\tv_accvgpr_read_b32 %13, %37\n\tv_accvgpr_read_b32 %14, %38\n\tv_accvgpr_read_b32 %15, %39\n\t"
