@@ -197,3 +197,35 @@ def test_full_size_batch_properties(synth_mod):
         d2 = sb.step(s)
         o2 = small.mpc_solve_host(d2["xref"][idx], d2["fsteps"][idx], s)
     assert np.array_equal(o2, out[idx])
+
+
+def test_nan_input_poisons_one_instance_only(oracle_mod, synth_mod):
+    """A NaN in one instance's reference trajectory: OSQP's residual tests all compare false, the solve runs to
+    max_iter and keeps its NaN iterate (store_solution only cold-starts on infeasible / non-convex statuses); the
+    other instances of the batch must not notice.  GPU and oracle must agree on iterations, status and NaN pattern."""
+    import qrw_hip
+
+    B, N, N_gait = 4, 16, 20
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=("trot",), seed0=20260500)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    refs = [oracle_mod.MPC(0.02, N, 0.02 * N, N_gait) for _ in range(B)]
+    for s in range(3):
+        d = sb.step(s)
+        xref = d["xref"].copy()
+        if s == 1:
+            xref[1, 7, 3] = np.nan  # a velocity entry of the bounds of instance 1
+            xref[3, 2, 5] = 1e300   # instance 3: overflow (Inf - Inf in the residuals): whatever OSQP's arithmetic does with it
+        out = eng.mpc_solve_host(xref, d["fsteps"], s)
+        st = eng.mpc_stats()
+        for b in range(B):
+            assert refs[b].run(s, xref[b], d["fsteps"][b]) == 0
+            ref = refs[b].get_latest_result()
+            assert st["iters"][b] == refs[b].iter and st["status"][b] == refs[b].status, (s, b, st["iters"][b], refs[b].iter,
+                                                                                         st["status"][b], refs[b].status)
+            assert np.array_equal(np.isnan(out[b]), np.isnan(ref)), (s, b)
+            ok = ~np.isnan(ref)
+            if ok.any():
+                assert np.abs(out[b][ok] - ref[ok]).max() <= RTOL * max(np.abs(ref[ok]).max(), 1e-12), (s, b)
+        if s >= 1:
+            assert np.isnan(out[1]).any() and np.isfinite(out[0]).all() and np.isfinite(out[2]).all()
+
