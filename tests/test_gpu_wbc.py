@@ -162,3 +162,28 @@ def test_async_wrapper_returns_previous_then_new_result(synth_mod):
         asyn.stop_parallel_loop()  # waits for the side stream, as polling newResult does in scripts/test_mpc.py:64
         a, b = asyn.get_latest_result(), sync.get_latest_result()
         assert np.array_equal(a, b)
+
+
+def test_contact_patterns_from_flight_to_full_stance(oracle_mod, synth_mod):
+    """Every one of the 16 contact sets (flight phase, single support, ..., four feet), changing from call to call on
+    the same solver instance (the QP's matrix changes, the warm start is kept): GPU vs oracle."""
+    import qrw_hip
+
+    B = 16
+    sb = synth_mod.SyntheticBatch(B, 16, gaits=("trot",), seed0=93000)
+    eng = qrw_hip.Batch(B)
+    refs = [oracle_mod.WbcController(0.002) for _ in range(B)]
+    rng = np.random.default_rng(5)
+    for s in range(4):
+        d = sb.step(s)
+        contacts = np.array([[(((b + 5 * s) % 16) >> i) & 1 for i in range(4)] for b in range(B)], dtype=np.float64)
+        f = f_cmd_for(contacts, rng)
+        o = eng.wbc_compute_host(d["q"], d["dq"], f, contacts, d["pgoals"], d["vgoals"], d["agoals"])
+        st = eng.wbc_stats()
+        for b in range(B):
+            r = refs[b]
+            r.compute(d["q"][b], d["dq"][b], f[b], contacts[b], d["pgoals"][b], d["vgoals"][b], d["agoals"][b])
+            assert st["iters"][b] == r.qp_iter, (s, b, contacts[b], st["iters"][b], r.qp_iter)
+            for key, ref in (("tau_ff", r.tau_ff), ("qdes", r.qdes), ("vdes", r.vdes[:, 0]),
+                             ("f_with_delta", r.f_with_delta[:, 0]), ("ddq_res", r.ddq_res)):
+                assert rel_err(o[key][b], ref) < RTOL, (s, b, key, contacts[b])
