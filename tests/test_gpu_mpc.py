@@ -229,3 +229,30 @@ def test_nan_input_poisons_one_instance_only(oracle_mod, synth_mod):
         if s >= 1:
             assert np.isnan(out[1]).any() and np.isfinite(out[0]).all() and np.isfinite(out[2]).all()
 
+
+
+def test_truncated_gait_keeps_stale_rows(oracle_mod, synth_mod):
+    """fsteps with an all-zero row before the horizon ends: construct_gait stops there (MPC.cpp:686-701), update_ML only
+    rewrites the B blocks and S flags of the rows before it and the later ones keep what earlier calls left
+    (MPC.cpp:418-464).  The cut moves from call to call, including to row 0 (nothing rewritten) and back to full length."""
+    import qrw_hip
+
+    B, N, N_gait = 6, 16, 20
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=("trot", "walk"), seed0=20260700)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    refs = [oracle_mod.MPC(0.02, N, 0.02 * N, N_gait) for _ in range(B)]
+    cuts = [[16, 16, 16, 16, 16, 16], [9, 16, 3, 12, 1, 16], [16, 5, 0, 12, 7, 15], [4, 16, 16, 0, 16, 2], [16, 16, 16, 16, 16, 16]]
+    for s, cut in enumerate(cuts):
+        d = sb.step(s)
+        fsteps = d["fsteps"].copy()
+        for b in range(B):
+            fsteps[b, cut[b]:, :] = 0.0
+        out = eng.mpc_solve_host(d["xref"], fsteps, s)
+        st = eng.mpc_stats()
+        for b in range(B):
+            assert refs[b].run(s, d["xref"][b], fsteps[b]) == 0
+            ref = refs[b].get_latest_result()
+            assert st["iters"][b] == refs[b].iter and st["status"][b] == refs[b].status, (s, b, st["iters"][b], refs[b].iter)
+            assert max(rel_err(out[b, :12], ref[:12]), rel_err(out[b, 12:], ref[12:])) < RTOL, (s, b)
+            gait, S = eng.mpc_gait(b)
+            assert np.array_equal(gait, refs[b].get_gait()), (s, b)
