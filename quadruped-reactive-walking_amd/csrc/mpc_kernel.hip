@@ -660,6 +660,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   for (int c = 0; c < 5; c++) aOC[c] = zeC[c] = 0.0;
   const double aVel = (j >= 2) ? alpha : 0.0;
   double wD[3];  // zeta - eta of the dynamics rows, as the next right-hand side needs it (first iteration: warm start)
+  // wD of the next horizon step (same foot / foot - 2): exchanged as soon as wD is final, one iteration ahead of its use
+  // in the right-hand side, so that the cross-lane round trip overlaps the rest of the update
+  double wnV[3] = {0.0, 0.0, 0.0}, wn6V[3] = {0.0, 0.0, 0.0};
   double rho_used = 1.0;  // rho of the current factorisation and loop constants
 
   // factor data (per lane: D_j^-1 of the foot's force block, two rows of the step's K^-1, 3 rows of Delta_k^-1)
@@ -781,6 +784,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
           for (int c = 0; c < 12; c++) Di[t][c].set(DiV[t][c]);
       }
+      nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);  // wD was re-based above
     PH(0);
     }  // need_factor
 
@@ -790,8 +794,6 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     for (int c = 0; c < 5; c++) wC[c] = zeC[c] - etC[c];
     double rX[3], rF[3], coneT[3];
     cone_apply_t(wC, mu, coneT);
-    double wnV[3], wn6V[3];
-    nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const double wn = wnV[t], wn6 = wn6V[t];
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         wD[t] = act ? -thD[t] : 0.0;
         etS[t] = fma(aOS[t], fh[t], etS[t]);  // force-enable rows: z is identically 0 (l = u = 0)
       }
+      nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
 #pragma unroll
       for (int c = 0; c < 5; c++) {
         const double s_ = fma(aOC[c], cv[c], (1.0 - alpha) * zeC[c]) + etC[c];
