@@ -69,6 +69,13 @@ __device__ __forceinline__ double swap_halves(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// 16-lane rows 0 <-> 1 and 2 <-> 3 of the same register (v_permlane16_swap with both operands the same VGPR)
+__device__ __forceinline__ double swap_rows16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %0\n\tv_permlane16_swap_b32 %1, %1" : "+v"(lo), "+v"(hi));
+  return __hiloint2double(hi, lo);
+}
+
 // Paired sweeps (compile-time N with an even number of steps per chain): an LDS read moves 64 lanes whatever EXEC says
 // (scripts/ubench/exec_rate.hip), and the chains only fill lanes 0..31.  So one set of reads fetches the operands of
 // TWO consecutive steps -- lanes 0..31 those of step 2p+1, lanes 32..63 those of step 2p+2 -- and the running vector
@@ -123,8 +130,9 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
       pair(b1, p + 1);
     }
   }
-  // root: chain A's last step sits in lanes 32..43, chain B's contribution (step LB, odd, exchanged) in lanes 48..59
-  x += shfl(pB, (lane & 15) + 48);
+  // root: chain A's last step sits in lanes 32..43 (row 2), chain B's contribution (step LB, odd, exchanged) in lanes
+  // 48..59 (row 3): a row exchange instead of an LDS round trip
+  x += swap_rows16(pB);
   if (lane >= 32 && lane < 44) sX[m * 12 + i] = x;
 }
 template <int NC>
