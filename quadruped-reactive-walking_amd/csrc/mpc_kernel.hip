@@ -54,7 +54,15 @@ struct alignas(16) MpcLdsT {
   unsigned long long sBal[2];
 };
 
-__device__ __forceinline__ void wg_sync() { __syncthreads(); }
+// Workgroup barrier of the ADMM loop.  One wavefront per instance: the LDS executes a wavefront's operations in order, so
+// no barrier and no drain of the LDS queue is needed between a phase's stores and the next phase's loads -- only the
+// compiler must keep their order.  (__syncthreads() would cost an s_waitcnt lgkmcnt(0) at every phase boundary.)
+template <int NW>
+__device__ __forceinline__ void wg_sync_t() {
+  if constexpr (NW == 1) asm volatile("" ::: "memory");
+  else __syncthreads();
+}
+#define wg_sync() wg_sync_t<NW>()
 #ifdef QRW_PROFILE_PHASES
 #define PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0,0,0,0,0,0,0,0,0,0};
 #ifndef QRW_PH_MASK
