@@ -316,7 +316,7 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
         for (int c = 0; c < 12; c++) Mout[i * 12 + c] = m[c];
       }
     }
-    __syncthreads();
+    wg_sync_t<NT / 64>();
     if (Di != nullptr) {
       const int kA = root ? mroot : ((s < nA) ? s : -1), kB = root ? -1 : ((s < nB) ? N - 1 - s : -1);
       if (k == kA || k == kB) {
@@ -360,7 +360,7 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
 #pragma unroll
       for (int c = 0; c < 12; c++) nn[c] = active ? nx[c] : nn[c];
     }
-    __syncthreads();
+    wg_sync_t<NT / 64>();
   }
 }
 
