@@ -255,6 +255,10 @@ class QPWBC:
     def status(self):
         return self._lib.qpwbc_oracle_status(self._h)
 
+    @property
+    def rho(self):
+        return self._lib.qpwbc_oracle_rho(self._h)
+
 
 class WbcController:
     """Oracle counterpart of scripts/QP_WBC.py wbc_controller (compute only)."""

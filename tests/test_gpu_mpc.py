@@ -256,3 +256,68 @@ def test_truncated_gait_keeps_stale_rows(oracle_mod, synth_mod):
             assert max(rel_err(out[b, :12], ref[:12]), rel_err(out[b, 12:], ref[12:])) < RTOL, (s, b)
             gait, S = eng.mpc_gait(b)
             assert np.array_equal(gait, refs[b].get_gait()), (s, b)
+
+
+def test_reference_known_answers_on_the_hip_path(oracle_mod):
+    """The reference's own scenarios (scripts/test_mpc.py:87-110 four-stance non-centred, :136-160 two-stance trot
+    centred; tests/trot_kat.py) driven through the HIP path as a batch of two, each instance with its own feedback
+    loop, 500 receding-horizon calls.  The reference's criteria must hold, and every call must take the same number
+    of ADMM iterations as the oracle fed the same inputs (the oracle is stepped on the HIP path's trajectory)."""
+    import qrw_hip
+    import trot_kat
+
+    N, NG = trot_kat.N, trot_kat.N_GAIT
+    eng = qrw_hip.Batch(2, n_steps=N, N_gait=NG, T_gait=0.32)
+    refs = [oracle_mod.MPC(0.02, N, 0.32, NG) for _ in range(2)]
+    xref = np.zeros((2, 12, N + 1))
+    xref[:, 2, :] = trot_kat.H_REF
+    xref[0, :, 0] = trot_kat.NOT_CENTERED  # instance 0: four-stance, non-centred
+    four = np.zeros((NG, 12))
+    four[:N, :] = [0.195, 0.147, 0., 0.195, -0.147, 0., -0.195, 0.147, 0., -0.195, -0.147, 0.]
+    plan = trot_kat.CompressedTrot()  # instance 1: two-stance trot, centred
+    worst = 0.0
+    for i in range(500):
+        fsteps = np.stack([four, plan.fsteps()])
+        out = eng.mpc_solve_host(xref, fsteps, i)
+        st = eng.mpc_stats()
+        assert (st["status"] == 1).all()
+        for b in range(2):
+            assert refs[b].run(i, xref[b], fsteps[b]) == 0
+            assert st["iters"][b] == refs[b].iter, (i, b, st["iters"][b], refs[b].iter)
+            r = refs[b].get_latest_result()
+            worst = max(worst, rel_err(out[b, :12], r[:12]), rel_err(out[b, 12:], r[12:]))
+        plan.roll()
+        xref[0, :, 0] = out[0, :12, 0]
+        if i > 0:
+            xref[1, :, 0] = out[1, :12, 0]
+    assert worst < RTOL
+    r = out[0]
+    assert np.allclose(r[12:, 0], np.tile(r[12:15, 0], 4)) and np.allclose(r[:12, 0], xref[0, :, 1], atol=1e-3)
+    assert np.allclose(out[1, :12, 0], xref[1, :, 1], atol=1e-2)
+
+
+def test_config2_batch256_mpc_only(oracle_mod, synth_mod):
+    """BASELINE config 2 (batch 256, N = 16, MPC only) at its full size: properties on every instance, oracle parity
+    (iterations, status, rho, 1e-4) on a spread of 24 of them over 4 receding-horizon calls."""
+    import qrw_hip
+
+    B, N = 256, 16
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot",), seed0=20260000)
+    eng = qrw_hip.Batch(B, N)
+    idx = np.arange(0, B, 11)[:24]
+    refs = {int(b): oracle_mod.MPC(0.02, N, 0.32, 20) for b in idx}
+    x0 = None
+    for s in range(4):
+        d = sb.step(s, x0)
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        st = eng.mpc_stats()
+        assert (st["status"] == 1).all() and (st["iters"] % 25 == 0).all()
+        for b, m in refs.items():
+            assert m.run(s, d["xref"][b], d["fsteps"][b]) == 0
+            r = m.get_latest_result()
+            assert st["iters"][b] == m.iter and np.isclose(st["rho"][b], m.rho, rtol=1e-9), (s, b)
+            assert max(rel_err(out[b, :12], r[:12]), rel_err(out[b, 12:], r[12:])) < RTOL
+        x0 = out[:, :12, 0]
+    f = out[:, 12:, :].transpose(0, 2, 1).reshape(B, N, 4, 3)
+    gait = d["gait"][:, :N]
+    assert np.abs(f[gait == 0]).max() < 1e-3 and (f[gait == 1][:, 2] > -1e-3).all()

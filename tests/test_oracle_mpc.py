@@ -1,7 +1,7 @@
 """Checks of the oracle's MPC restatement (oracle/mpc_oracle.c <- /root/reference/src/MPC.cpp).
 
 Pins available: the analytic properties asserted by the reference's stale
-scripts/test_mpc.py:54-85,136-160; the structural invariants of the QP; an independent dense
+scripts/test_mpc.py:54-110,136-190 (tests/trot_kat.py); the structural invariants of the QP; an independent dense
 assembly of the QP from the documented equations (scripts/Documentation/Equations_MPC_22_02_2020.tex:348-616);
 the optimality conditions of the solved QP.  No numeric vectors exist in the reference.
 """
@@ -169,3 +169,117 @@ def test_first_call_uses_default_footholds_then_fsteps(oracle_mod, synth_mod):
     assert not np.allclose(m1.get_latest_result(), m2.get_latest_result())
     # an un-setup object refuses num_iter != 0 (the reference would dereference a null workspace)
     assert oracle_mod.MPC(DT, N, 0.32, 20).run(3, d["xref"][0], d["fsteps"][0]) != 0
+
+
+def test_fourstance_not_centered_known_answer(oracle_mod):
+    """scripts/test_mpc.py:87-110: four-stance, non-centred start, 500 receding-horizon calls: equal foot forces and
+    first predicted state within 1e-3 of the reference state."""
+    import trot_kat
+
+    N = trot_kat.N
+    m = oracle_mod.MPC(DT, N, 0.32, trot_kat.N_GAIT)
+    xref = np.zeros((12, N + 1))
+    xref[2, :] = trot_kat.H_REF
+    xref[:, 0] = trot_kat.NOT_CENTERED
+    fsteps = np.zeros((trot_kat.N_GAIT, 12))
+    fsteps[:N, :] = [0.195, 0.147, 0., 0.195, -0.147, 0., -0.195, 0.147, 0., -0.195, -0.147, 0.]
+    for i in range(500):
+        assert m.run(i, xref, fsteps) == 0
+        r = m.get_latest_result()
+        xref[:, 0] = r[:12, 0]
+    assert np.allclose(r[12:, 0], np.tile(r[12:15, 0], 4))  # :109 (default tolerances, as in the reference)
+    assert np.allclose(r[:12, 0], xref[:, 1], atol=1e-3)  # :110
+    assert abs(r[14::3, 0].sum() - 9.81 * 2.50000279) < 1e-3
+
+
+def test_twostance_centered_known_answer(oracle_mod):
+    """scripts/test_mpc.py:136-160: two-stance trot (FL+HR / FR+HL, period 0.32 s) with the reference's
+    receding-horizon roll (:96-133), centred start, 500 calls: first predicted state within 1e-2 of the reference
+    state.  Inputs and criterion are the reference's own (tests/trot_kat.py restates them for today's API)."""
+    import trot_kat
+
+    m = oracle_mod.MPC(DT, trot_kat.N, 0.32, trot_kat.N_GAIT)
+    stats = []
+
+    def solve(i, xref, fsteps):
+        assert m.run(i, xref, fsteps) == 0
+        stats.append((m.iter, m.status))
+        return m.get_latest_result()
+
+    x_f, xref = trot_kat.run_twostance(solve, 500, centered=True)
+    assert np.allclose(x_f[:12, 0], xref[:, 1], atol=1e-2), x_f[:12, 0] - xref[:, 1]  # :160
+    fz = x_f[14::3, 0]
+    assert abs(fz.sum() - 9.81 * 2.50000279) < 0.05 and (fz >= -1e-6).all()  # two stance feet carry the body
+    assert (np.array(stats)[:, 1] == 1).all()  # OSQP_SOLVED on every call
+
+
+def _exact_equality_qp(i, xref, fsteps, N):
+    """The optimum of the MPC QP when no cone row is active: equality-constrained QP (dynamics rows + force-enable
+    rows of the swing feet) solved through its dense KKT system.  No ADMM, no oracle code: numpy + dense_qp only."""
+    A, lo, up, Pd = dense_qp(xref, fsteps, N, first_call=(i == 0))
+    gait = fsteps[:N, 0::3] != 0
+    rows = list(range(12 * N)) + [12 * N + 12 * k + 3 * f + c for k in range(N) for f in range(4) if not gait[k, f]
+                                  for c in range(3)]
+    Ae, be = A[rows], up[rows]
+    n, me = 24 * N, len(rows)
+    K = np.zeros((n + me, n + me))
+    K[:n, :n] = np.diag(Pd)
+    K[:n, n:] = Ae.T
+    K[n:, :n] = Ae
+    sol = np.linalg.solve(K, np.concatenate([np.zeros(n), be]))[:n]
+    Ax = A @ sol
+    cone = slice(24 * N, 44 * N)
+    assert (Ax[cone] <= up[cone] + 1e-9).all() and (Ax[cone] >= lo[cone] - 1e-9).all()  # inactive, as assumed
+    r = np.zeros((24, N))
+    r[:12] = sol[:12 * N].reshape(N, 12).T + xref[:, 1:]
+    r[12:] = sol[12 * N:].reshape(N, 12).T
+    return r
+
+
+def test_twostance_not_centered_criterion_is_not_met_by_the_qp_as_written(oracle_mod, monkeypatch):
+    """scripts/test_mpc.py:162-190 (non-centred start, 2000 calls, within 1e-2) is STALE with respect to
+    src/MPC.cpp: with the QP exactly as written there (weights :330: roll/pitch 0.25, roll/pitch rate 0) the closed
+    loop `state := first predicted state` of this two-stance scenario is linearly unstable, so the criterion cannot be
+    met by ANY exact solver of that QP.  Shown without the oracle's solver or assembly: for a start 1 % of the way to
+    the reference's non-centred state no cone row is ever active, the optimum is an equality-constrained QP solved by
+    one dense KKT system, and that closed loop grows by ~1.19 per gait period; the oracle follows it.  (The same holds
+    for the older weight set left in the comment at :329.)  The reference's own start state then saturates f_z = 25
+    within the first call and leaves the neighbourhood altogether."""
+    import trot_kat
+
+    N = trot_kat.N
+    centre = np.zeros(12)
+    centre[2] = trot_kat.H_REF
+    monkeypatch.setattr(trot_kat, "NOT_CENTERED", centre + 0.01 * (trot_kat.NOT_CENTERED - centre))
+    m = oracle_mod.MPC(DT, N, 0.32, trot_kat.N_GAIT)
+    err_o, err_e = [], []
+
+    def solve_oracle(i, xref, fsteps):
+        assert m.run(i, xref, fsteps) == 0 and m.status == 1
+        r = m.get_latest_result()
+        err_o.append(r[:12, 0] - xref[:, 1])
+        return r
+
+    def solve_exact(i, xref, fsteps):
+        r = _exact_equality_qp(i, xref, fsteps, N)
+        err_e.append(r[:12, 0] - xref[:, 1])
+        return r
+
+    calls = 161
+    trot_kat.run_twostance(solve_oracle, calls, centered=False)
+    trot_kat.run_twostance(solve_exact, calls, centered=False)
+    eo, ee = np.abs(np.array(err_o)).max(axis=1), np.abs(np.array(err_e)).max(axis=1)
+    # same phase of the gait, one / ten periods apart: growth, not decay, in both
+    assert ee[160] > 2.0 * ee[32] and eo[160] > 2.0 * eo[32], (eo[::16], ee[::16])
+    # the oracle (eps 1e-6 ADMM, warm-started) tracks the exact optimum's closed loop while the deviation is small
+    assert np.abs(np.array(err_o)[:64] - np.array(err_e)[:64]).max() < 1e-3
+    # and from the reference's own start the criterion of :190 is far from met already after 400 calls
+    monkeypatch.undo()
+    m2 = oracle_mod.MPC(DT, N, 0.32, trot_kat.N_GAIT)
+
+    def solve2(i, xref, fsteps):
+        assert m2.run(i, xref, fsteps) == 0
+        return m2.get_latest_result()
+
+    x_f, xref = trot_kat.run_twostance(solve2, 400, centered=False)
+    assert np.abs(x_f[:12, 0] - xref[:, 1]).max() > 1.0

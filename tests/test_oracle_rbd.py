@@ -149,3 +149,36 @@ def test_invkin_matches_formulas(oracle_mod):
         assert np.allclose(ddq[3 * i:3 * i + 3], iJ @ a, rtol=1e-10, atol=1e-10)
         assert np.allclose(ik.get_dq_cmd()[3 * i:3 * i + 3], iJ @ vgoals[:, i], rtol=1e-10, atol=1e-12)
         assert np.allclose(ik.get_q_step()[3 * i:3 * i + 3], iJ @ e, rtol=1e-10, atol=1e-12)
+
+
+def test_composite_inertia_and_com_vs_mpc_constants(oracle_mod):
+    """The MPC hard-codes the trunk+legs composite inertia `gI` (src/MPC.cpp:25-26) and a CoM 0.03 below the base
+    (`offset_CoM`, :21); the WBC gets both from the URDF through Pinocchio.  The URDF is absent here and
+    include/qrw_solo12_model.h restates it from memory, so this records how far the restated model's composite
+    body is from the constants the reference embeds: diagonal within ~5 % (standing pose 0.7/-1.4) resp. ~3 %
+    (0.8/-1.6, scripts/Estimator.py:245), CoM 0.024-0.026 below the base instead of 0.03, off-diagonal terms of
+    the same order of magnitude at most.  It is a MEASURED residual risk of the unpinned model constants, not a parity
+    claim: the MPC path uses gI itself (as the reference does) and never this model."""
+    GI = np.array([[3.09249e-2, -8.00101e-7, 1.865287e-5], [-8.00101e-7, 5.106100e-2, 1.245813e-4],
+                   [1.865287e-5, 1.245813e-4, 6.939757e-2]])
+    measured = {}
+    for ang, tol in ((0.7, 0.055), (0.8, 0.03)):
+        q = np.zeros(19)
+        q[6] = 1.0
+        q[7:] = [0, ang, -2 * ang, 0, ang, -2 * ang, 0, -ang, 2 * ang, 0, -ang, 2 * ang]
+        M = oracle_mod.crba(q)[:6, :6]
+        m = M[0, 0]
+        # spatial inertia about the base origin: [[m 1, -m [c]x], [m [c]x, I_o]]
+        c = -np.array([M[4, 2], M[5, 0], M[3, 1]]) / m
+        cx = np.array([[0, -c[2], c[1]], [c[2], 0, -c[0]], [-c[1], c[0], 0]])
+        assert np.allclose(M[3:, :3], m * cx, atol=1e-12) and np.allclose(M[:3, 3:], -m * cx, atol=1e-12)
+        Ic = M[3:, 3:] + m * cx @ cx  # parallel axis: about the CoM
+        rel = np.diag(Ic) / np.diag(GI) - 1.0
+        measured[ang] = (c[2], rel)
+        assert abs(m - MASS) < 1e-12
+        assert np.abs(rel).max() < tol, (ang, rel)
+        assert -0.03 < c[2] < -0.02 and abs(c[0]) < 1e-4 and abs(c[1]) < 1e-12, c
+        off = np.abs(Ic - np.diag(np.diag(Ic))).max()
+        assert off < 2e-4  # gI's largest off-diagonal term is 1.25e-4
+    # measured (2026-10, this model file): c_z -0.02639 / -0.02403; diag +1.3 % +5.3 % -0.6 % / -3.0 % +0.8 % -1.9 %
+    assert abs(measured[0.7][0] + 0.02639) < 1e-4 and abs(measured[0.8][0] + 0.02403) < 1e-4
