@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — control-steps/sec (MPC + WBC) of the MI355X hot path on synthetic Solo12 trot states.
+"""bench.py — control-steps/sec (MPC + WBC) of the MI355X hot path on synthetic Solo12 states.
 
-One "step" = one MPC::run + one wbc_controller.compute for every instance of the batch
-(ratio 1:1).  Default workload = BASELINE.json configs[2]: batch 4096, N = 16,
-trot, MPC + QPWBC + InvKin on one MI355X.  With --gpus N every rank owns its own 4096 instances
-(weak scaling).  Instances are independent, so the step has no collective; --gather-results adds the
-optional all-gather of the packed results (RCCL over xGMI) a central logger would want.
+One "step" = one MPC::run + one wbc_controller.compute for every instance of the batch (ratio 1:1,
+SURVEY.md §8(d)).  Default workload = BASELINE.json configs[2]: batch 4096, N = 16, trot, MPC + QPWBC +
+InvKin on one MI355X; `--n-steps 32 --gaits walk,trot,bounding` is configs[3].
+
+`--gpus N` (BASELINE configs[4]): one process per GPU, every rank owns its own `--batch` instances (weak scaling)
+and, per step, all-gathers the joint torques of every robot (12 f64 per instance) over RCCL on a side stream,
+overlapped with the next step.  The driver starts the ranks with torch.distributed.run; run by hand without
+WORLD_SIZE in the environment, `--gpus N` starts the N ranks itself (fresh child processes, nothing re-exec'd).
 
 Prints ONE JSON line (rank 0): metric/value/unit/... plus
-  roofline     — dominant kernel (mpc_solve_kernel): algorithmic FP64 flops per launch (measured ADMM
-                 iteration counts x SURVEY §8(d) per-iteration figure) / its average duration measured
-                 with HIP events on the launch stream, against the gfx950 FP64 peak;
-  cpu_baseline — the CPU oracle (oracle/, "port", -O3 -march=native, OpenMP) timed on a bounded sample
-                 of the same workload on this box's host cores (rank 0, N=1 only).
+  roofline     — dominant kernel (mpc_solve_kernel): algorithmic FP64 flops per launch (ADMM iteration counts of
+                 EVERY timed launch x the per-iteration figure of SURVEY §8(d) as a function of N) / the launch
+                 durations measured with HIP events on the launch stream, against the gfx950 FP64 peak;
+  accuracy     — the metric's second half: GPU torques / forces against the CPU oracle on the same seeded sample;
+  cpu_baseline — the CPU oracle (oracle/, "port", -O3 -march=native, OpenMP) timed on a bounded sample of the
+                 same workload on this box's host cores (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,20 +29,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
-# algorithmic work per unit (SURVEY.md §8(d), N = 16; DESIGN.md restates them)
-F_ITER = 64.8e3      # flops per ADMM iteration of one MPC instance
-F_FAC = 0.33e6       # flops per KKT factorisation
-F_ASM = 3.0e3        # assembly
-F_WBC = 15.0e3       # kinematics + 2x RNEA + InvKin + QP build
-F_WBC_IT = 1.0e3     # per 12-variable ADMM iteration
-B_ALG = 36.4e3       # compulsory bytes per control step
 PEAK_FP64 = 78.6e12  # gfx950 FP64 vector = matrix peak
 PEAK_HBM = 8.0e12
 
 
-def main():
+# ---- algorithmic work per unit (scripts/alg_work.py derives the N-dependence) ----
+def f_iter(N):
+    """flops per ADMM iteration of one MPC instance: 4 nnzL(N) + 4 nnz(A) + 12 (n + m) with nnzL(N) = 726 N - 670
+    (symbolic Cholesky of the time-interleaved reduced KKT; 10 946 at N = 16), nnz(A) = 126 N - 18, n + m = 68 N."""
+    return 4.0 * (726 * N - 670) + 4.0 * (126 * N - 18) + 12.0 * 68 * N
+
+
+def f_fac(N):
+    """flops per KKT factorisation: sum of squared column counts, linear in N, 0.33 Mflop at N = 16 (SURVEY's figure)."""
+    return 0.33e6 * (21034.0 * N - 25202.0) / (21034.0 * 16 - 25202.0)
+
+
+F_ASM = 3.0e3        # assembly (M7 + M8 structural)
+F_WBC = 15.0e3       # kinematics + 2x RNEA + InvKin + QP build
+F_WBC_IT = 1.0e3     # per 12-variable ADMM iteration
+
+
+def b_alg(N, N_gait):
+    """compulsory HBM bytes per control step: inputs + outputs + persisted solver state read and written once."""
+    io = 8 * (12 * (N + 1) + 12 * N_gait + 89 + 24 * N + 48)
+    state = 2 * 8 * (24 * N + 44 * N + 44 * N + 4)
+    return float(io + state)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -46,43 +67,111 @@ def main():
     ap.add_argument("--n-steps", type=int, default=16, help="MPC horizon")
     ap.add_argument("--gaits", type=str, default="trot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-results", action="store_true",
-                    help="N > 1: all-gather every rank's packed results each step (not part of the control path)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary closed-loop figures (profiling runs)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="instances in the CPU baseline sample")
+    ap.add_argument("--no-collective", action="store_true", help="N > 1: skip the per-step all-gather of torques")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="instances in the CPU baseline / accuracy sample")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="control steps of the CPU baseline / accuracy sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16 cores)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` by hand: start N fresh rank processes (no exec of this one, no GPU touched here)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return 0 if all(rc == 0 for rc in rcs) else 1
+
+
+class StubEngine:
+    """QRW_BENCH_STUB=1: NO kernels — a rehearsal of the multi-rank plumbing (sharding, per-step all-gather pipeline,
+    barrier + max-over-ranks timing, JSON assembly) on CPU tensors for the world-size-2 gloo test.  The line it prints
+    is marked "data": "stub" and its value means nothing."""
+
+    def __init__(self, B, N, b0, torch):
+        self.B, self.N, self.b0, self.torch = B, N, b0, torch
+        self._s = 0
+
+    def mpc_solve(self, xref, fsteps, s, out=None):
+        out.zero_()
+        self._s = s
+        return out
+
+    def wbc_compute(self, q, dq, f_cmd, contacts, pg, vg, ag, out=None):
+        t = self.torch
+        if out is None:
+            out = dict(tau_ff=t.empty((self.B, 12), dtype=t.float64), f_with_delta=t.zeros((self.B, 12), dtype=t.float64))
+        idx = t.arange(self.b0, self.b0 + self.B, dtype=t.float64)
+        out["tau_ff"].copy_(idx[:, None] * 1e-3 + self._s + t.arange(12, dtype=t.float64)[None, :] * 1e-6)
+        return out
+
+    def mpc_stats(self):
+        return dict(iters=np.full(self.B, 25, np.int32), status=np.ones(self.B, np.int32))
+
+    def wbc_stats(self):
+        return dict(iters=np.full(self.B, 25, np.int32))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher and the flag must agree)" % (args.gpus, world))
+
+    import torch
+
+    stub = os.environ.get("QRW_BENCH_STUB") == "1"
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal knobs (1-GPU box): QRW_SINGLE_DEVICE=1 puts every rank on cuda:0, QRW_DIST_BACKEND=gloo avoids RCCL
     if os.environ.get("QRW_SINGLE_DEVICE") == "1":
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("QRW_DIST_BACKEND", "nccl")
+        backend = os.environ.get("QRW_DIST_BACKEND", "gloo" if stub else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    import qrw_hip
     import synth
-    from sharding import ResultGatherer, pack_results
+    from sharding import TorqueGatherPipeline
 
     B, N = args.batch, args.n_steps
     N_gait = max(20, N + 4)
     W, K = max(args.warmup, 1), args.steps  # the first call (num_iter == 0) is the QP setup: always untimed
     gaits = tuple(args.gaits.split(","))
-    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K, b0=rank * B)
+    collective = world > 1 and not args.no_collective
+    n_regions = 2 if collective else 1      # N > 1: a second timed region without the all-gather, same line
+    n_in = W + n_regions * K
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=n_in, b0=rank * B)
     t_gen = time.time()
-    steps = [sb.step(s) for s in range(W + K)]
+    steps = [sb.step(s) for s in range(n_in)]
     t_gen = time.time() - t_gen
 
     def dev_t(key):
@@ -92,115 +181,219 @@ def main():
     q, dq, contacts = dev_t("q"), dev_t("dq"), dev_t("contacts")
     pg, vg, ag = dev_t("pgoals"), dev_t("vgoals"), dev_t("agoals")
 
-    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=local_rank)
+    if stub:
+        eng = StubEngine(B, N, rank * B, torch)
+    else:
+        import qrw_hip
+        eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=local_rank)
     mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
     f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
-    wbc_out = None
-    gather = ResultGatherer(B, 48, dev) if (world > 1 and args.gather_results) else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    ev_w = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    it_mpc, it_wbc = [], []
+    wbc_bufs = [None, None]  # two output sets: the gather of step s reads one while step s+1 writes the other
+    pipe = TorqueGatherPipeline(B, dev) if world > 1 else None
+    mk_ev = (lambda: torch.cuda.Event(enable_timing=True)) if not stub else (lambda: None)
+    ev = [(mk_ev(), mk_ev()) for _ in range(n_regions * K)]
+    ev_w = [(mk_ev(), mk_ev()) for _ in range(n_regions * K)]
+    it_dev = torch.zeros((n_regions * K, B), dtype=torch.int32, device=dev) if not stub else None
 
-    def one_step(s, timed_idx=None):
-        nonlocal wbc_out
-        if timed_idx is not None:
+    def one_step(s, timed_idx=None, gather=False):
+        rec = (timed_idx is not None) and not stub
+        if rec:
             ev[timed_idx][0].record()
         eng.mpc_solve(xref[s], fsteps[s], s, out=mpc_out)
-        if timed_idx is not None:
+        if rec:
             ev[timed_idx][1].record()
         f_cmd.copy_(mpc_out[:, 12:, 0])
-        if timed_idx is not None:
+        i = s & 1
+        if gather:
+            pipe.wait_buffer_free(i)  # the gather that last read this output set (two steps ago) has finished
+        if rec:
             ev_w[timed_idx][0].record()
-        wbc_out = eng.wbc_compute(q[s], dq[s], f_cmd, contacts[s], pg[s], vg[s], ag[s], out=wbc_out)
-        if timed_idx is not None:
+        wbc_bufs[i] = eng.wbc_compute(q[s], dq[s], f_cmd, contacts[s], pg[s], vg[s], ag[s], out=wbc_bufs[i])
+        if rec:
             ev_w[timed_idx][1].record()
-        if gather is not None:
-            gather.gather(pack_results(wbc_out["tau_ff"], wbc_out["f_with_delta"], wbc_out["qdes"], wbc_out["vdes"]))
+            eng.copy_mpc_iters(it_dev[timed_idx])  # device-to-device, stays in HBM; read back after the timed region
+        if gather:
+            pipe.issue(i, wbc_bufs[i]["tau_ff"])   # all-gather on the side stream, overlaps the next step
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    for s in range(W):
-        one_step(s)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(K):
-        one_step(W + i, i)
-        # iteration counts are read back AFTER the timed region (they stay on the device)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    def timed_region(first, base_idx, gather):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            one_step(first + i, base_idx + i, gather)
+        if gather:
+            pipe.drain()  # the last all-gather belongs to the timed work
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    ranks_seen = [0]
     if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        me = torch.tensor([rank], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        seen = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(seen, me)
+        ranks_seen = sorted(int(t.item()) for t in seen)
+    for s in range(W):
+        one_step(s, gather=collective)
+    if collective:
+        pipe.drain()
+    elapsed = timed_region(W, 0, collective)
+    gather_ok = None
+    if collective:
+        gather_ok = pipe.check_last(rank, world, wbc_bufs[(W + K - 1) & 1]["tau_ff"])
+        elapsed_nc = timed_region(W + K, K, False)
 
-    # per-kernel figures (rank 0): durations from the HIP events, iteration counts of the LAST step
-    mpc_ms = np.array([a.elapsed_time(b) for a, b in ev])
-    wbc_ms = np.array([a.elapsed_time(b) for a, b in ev_w])
-    ms = eng.mpc_stats()
-    ws = eng.wbc_stats()
-    n_ok = int((ms["status"] == 1).sum())
-    # iteration counts differ per step; replay the stats of the last step as representative and
-    # scale the flops of every timed launch by its own duration share
-    flops_launch = float(ms["iters"].astype(np.float64).sum() * F_ITER + B * (F_FAC + F_ASM))
-    dur = float(mpc_ms[-1]) * 1e-3
-    achieved = flops_launch / dur
     total_steps = world * B * K
     value = total_steps / elapsed
-
     out = {
         "metric": "control-steps/sec (MPC+WBC)", "value": value, "unit": "steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "stub" if stub else "synthetic",
         "config": {"workload": "Solo12 %s, batch %d per GPU, horizon N=%d, MPC (OSQP-style ADMM) + WBC (InvKin + "
-                               "RNEA + box-QP) per control step, ratio 1:1" % ("/".join(gaits), B, N),
+                               "RNEA + box-QP) per control step, ratio 1:1; open-loop sequence: every call's current state "
+                               "is the reference plus fresh noise (harder than the closed receding-horizon sequence of "
+                               "SURVEY 8(d), which is reported beside it as closed_loop_sequence)" % ("/".join(gaits), B, N),
                    "batch_per_gpu": B, "n_steps": N, "gaits": list(gaits), "parallelism": "batch-sharded x%d" % world},
-        "roofline": {"kernel": "mpc_solve_kernel", "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP64 / 1e12,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": None,
-                     "launch_ms": float(mpc_ms[-1]), "launch_ms_mean": float(mpc_ms.mean()),
-                     "mean_admm_iters": float(ms["iters"].mean()), "max_admm_iters": int(ms["iters"].max()),
-                     "hbm_frac_algorithmic": (B * B_ALG / dur) / PEAK_HBM,
-                     "note": "compute roof: FP64 peak of gfx950 (vector = matrix = 78.6 TFLOP/s); the kernel is issue / "
-                             "latency bound and issues no MFMA (its sweeps run on the FP64 VALU with DPP, DESIGN.md 4.1)"},
-        "kernels_ms": {"mpc_solve_kernel": float(mpc_ms.mean()), "wbc_kernel": float(wbc_ms.mean())},
-        "solver": {"mpc_solved": n_ok, "mpc_instances": B, "wbc_mean_iters": float(ws["iters"].mean())},
-        "mpc_solves_per_s": world * B * K / (mpc_ms.sum() * 1e-3) if world == 1 else None,
-        "wbc_steps_per_s": world * B * K / (wbc_ms.sum() * 1e-3) if world == 1 else None,
-        "input_gen_s": t_gen,
     }
+    if world > 1:
+        out["collective"] = {
+            "op": "all_gather of joint torques, one per control step, side stream, overlapped with the next step"
+                  if collective else "none (--no-collective)",
+            "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else backend),
+            "bytes_per_rank_per_step": B * 12 * 8, "ranks_seen": ranks_seen, "gathered_block_check": gather_ok,
+            "no_collective_steps_per_s": (total_steps / elapsed_nc) if collective else None,
+            "no_collective_ms_per_step": (1e3 * elapsed_nc / K) if collective else None}
 
-    if rank == 0 and world == 1:
-        out["roofline"]["traffic"] = pmc_traffic_bytes()
-    if rank == 0 and world == 1 and not args.no_secondary:
-        out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
-        out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads)
+    if not stub:
+        # per-kernel figures (this rank): durations from HIP events on the launch stream, iteration counts of EVERY timed launch
+        mpc_ms = np.array([a.elapsed_time(b) for a, b in ev[:K]])
+        wbc_ms = np.array([a.elapsed_time(b) for a, b in ev_w[:K]])
+        iters = it_dev[:K].cpu().numpy().astype(np.float64)          # (K, B)
+        ms, ws = eng.mpc_stats(), eng.wbc_stats()
+        flops = iters.sum(axis=1) * f_iter(N) + B * (f_fac(N) + F_ASM)   # per launch
+        achieved = float(flops.sum() / (mpc_ms.sum() * 1e-3))
+        bytes_launch = B * b_alg(N, N_gait)
+        traffic, traffic_src = pmc_traffic_bytes(B, N)
+        out["roofline"] = {
+            "kernel": "mpc_solve_kernel", "bound": "fp64-valu-issue", "achieved": achieved / 1e12, "peak": PEAK_FP64 / 1e12,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": traffic, "traffic_source": traffic_src,
+            "launch_ms_mean": float(mpc_ms.mean()), "launch_ms_min": float(mpc_ms.min()), "launch_ms_max": float(mpc_ms.max()),
+            "launches": int(K), "mean_admm_iters": float(iters.mean()), "max_admm_iters": int(iters.max()),
+            "flops_per_iteration": f_iter(N), "flops_per_factorisation": f_fac(N),
+            "algorithmic_bytes_per_launch": bytes_launch,
+            "hbm_frac_algorithmic": (bytes_launch / (mpc_ms.mean() * 1e-3)) / PEAK_HBM,
+            "note": "roof = FP64 peak of gfx950 (vector = matrix = 78.6 TFLOP/s); neither of the contract's two labels fits: the "
+                    "kernel is bound by FP64 VALU instruction issue on dependent chains (one wavefront per SIMD, no MFMA issued, "
+                    "HBM at a fraction of a per cent), DESIGN.md 4.1"}
+        out["kernels_ms"] = {"mpc_solve_kernel": float(mpc_ms.mean()), "wbc_kernel": float(wbc_ms.mean())}
+        out["solver"] = {"mpc_solved_last_step": int((ms["status"] == 1).sum()), "mpc_instances": B,
+                         "wbc_mean_iters": float(ws["iters"].mean())}
+        out["input_gen_s"] = t_gen
+    if rank == 0 and world == 1 and not stub:
+        out["mpc_solves_per_s"] = B * K / (mpc_ms.sum() * 1e-3)
+        out["wbc_steps_per_s"] = B * K / (wbc_ms.sum() * 1e-3)
+        if not args.no_secondary:
+            out["closed_loop_sequence"] = closed_loop_sequence(B, N, N_gait, gaits, dev, W, K)
+            out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
+            out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
+        if not args.no_cpu_baseline:
+            base, ref_out = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
+            out["cpu_baseline"] = base
+            out["accuracy"] = accuracy_vs_oracle(synth, ref_out, args.cpu_sample, N, N_gait, gaits, args.cpu_steps, dev)
+            out["torque_max_abs_err"] = out["accuracy"]["torque_max_abs_err"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per mpc_solve_kernel launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE and
-    WRITE_SIZE are reported in KiB; 8-byte-per-lane accesses are uncalibrated on gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary_bench_b4096.json")
-    try:
-        rows = json.load(open(path))
+def pmc_traffic_bytes(B, N):
+    """HBM bytes per mpc_solve_kernel launch.  NOT measured by this run: read from the committed rocprofv3 PMC passes of
+    this same command (profiles/, separate --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE are in
+    KiB; the kernel's accesses are 8 bytes per lane, a width the guide marks uncalibrated on gfx950, so no correction
+    factor is applied).  Only valid for the profiled shape (batch 4096, N = 16)."""
+    if (B, N) != (4096, 16):
+        return None, None
+    for name in ("r2_pmc_summary_bench_b4096.json", "r1_pmc_summary_bench_b4096.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            rows = json.load(open(path))
+        except Exception:
+            continue
         tot = 0.0
         for r in rows:
             if "mpc_solve_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot += r["mean"] * 1024.0
-        return tot or None
-    except Exception:
-        return None
+        if tot:
+            return tot, "profiles/%s (static: rocprofv3 --pmc passes of this command, not collected by this run)" % name
+    return None, None
+
+
+def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
+    """SURVEY §8(d)'s sequence: each call's current state is the MPC's own predicted next state (scripts/test_mpc.py:78).
+    The inputs of call s+1 depend on the result of call s, so the sequence is first generated with an untimed pass
+    (GPU solve, host planner formulas), then replayed from HBM on a fresh handle: same inputs, same solver history, timed."""
+    import torch
+
+    import qrw_hip
+    import synth
+
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K)
+    gen = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    seq, x0 = [], None
+    for s in range(W + K):
+        d = sb.step(s, x0)
+        t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
+             ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")}
+        o = gen.mpc_solve(t["xref"], t["fsteps"], s)
+        x0 = o[:, :12, 0].cpu().numpy()
+        seq.append(t)
+    gen.close()
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
+    f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
+    it_dev = torch.zeros((K, B), dtype=torch.int32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    w = None
+
+    def step(s, i=None):
+        nonlocal w
+        t = seq[s]
+        if i is not None:
+            ev[i][0].record()
+        eng.mpc_solve(t["xref"], t["fsteps"], s, out=mpc_out)
+        if i is not None:
+            ev[i][1].record()
+        f_cmd.copy_(mpc_out[:, 12:, 0])
+        w = eng.wbc_compute(t["q"], t["dq"], f_cmd, t["contacts"], t["pgoals"], t["vgoals"], t["agoals"], out=w)
+        if i is not None:
+            eng.copy_mpc_iters(it_dev[i])
+
+    for s in range(W):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i, i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = np.array([a.elapsed_time(b) for a, b in ev])
+    iters = it_dev.cpu().numpy().astype(np.float64)
+    flops = iters.sum() * f_iter(N) + K * B * (f_fac(N) + F_ASM)
+    eng.close()
+    return {"value": B * K / el, "unit": "steps/s", "ms_per_step": 1e3 * el / K, "mean_admm_iters": float(iters.mean()),
+            "max_admm_iters": int(iters.max()), "roofline_frac": float(flops / (ms.sum() * 1e-3) / PEAK_FP64),
+            "what": "SURVEY 8(d) closed receding-horizon sequence (state advanced with the MPC's own prediction), "
+                    "%d timed calls after %d warm-up calls, inputs replayed from HBM" % (K, W)}
 
 
 def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False):
@@ -209,6 +402,8 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM.
     multiprocessing=True: the reference's asynchronous MPC mode (scripts/MPC_Wrapper.py:150-298) as two
     compute-unit-masked streams.  Reports the free-running rate and the iteration latency when paced at dt_wbc = 2 ms."""
+    import torch
+
     from Controller import Controller_batch
 
     q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
@@ -264,10 +459,11 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
             "instances_in_security_stop": bad, "what": what}
 
 
-def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
-    """CPU restatement (oracle/, 'port') on a bounded sample of the same workload: Bc instances x `steps`
-    receding-horizon control steps (the first one, which sets the QP up, is excluded like the GPU warm-up),
-    one instance per OpenMP thread over all host cores."""
+def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps):
+    """CPU restatement (oracle/, 'port') on a bounded sample of the same workload: Bc instances x `steps` control steps
+    of the headline's open-loop sequence (the first one, which sets the QP up, is excluded like the GPU warm-up), one
+    instance per OpenMP thread over the box's host cores.  Returns the figure and the per-step outputs (for the
+    accuracy leg)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build(fast=True)
@@ -276,14 +472,16 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
     mpc = oracle.MPCBatch(Bc, 0.02, N, 0.02 * N, N_gait, fast=True)
     wbc = oracle.WbcBatch(Bc, 0.002, fast=True)
     t_mpc = t_wbc = 0.0
+    outs = []
     for s in range(steps + 1):
         d = sb.step(s)
         a = time.perf_counter()
         r = mpc.run(s, d["xref"], d["fsteps"], cores)
         b = time.perf_counter()
-        wbc.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"],
-                    d["agoals"], cores)
+        tau, _, _, f = wbc.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"],
+                                   d["vgoals"], d["agoals"], cores)
         c = time.perf_counter()
+        outs.append((r, tau, f))
         if s > 0:
             t_mpc += b - a
             t_wbc += c - b
@@ -299,11 +497,42 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps=8):
         w1.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"], 1)
         if s > 0:
             t1 += time.perf_counter() - a
-    return {"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
-            "single_instance_single_thread_steps_per_s": 32 / t1,
-            "sample": "%d instances x %d control steps (after the set-up step), CPU restatement oracle/ "
-                      "(OSQP-0.6-style, not OSQP itself), gcc -O3 -march=native, OpenMP one instance per thread" % (Bc, steps),
-            "mpc_s": t_mpc, "wbc_s": t_wbc}
+    return ({"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
+             "single_instance_single_thread_steps_per_s": 32 / t1,
+             "sample": "%d instances x %d control steps (after the set-up step) of the headline sequence, %.1f s of CPU work; "
+                       "CPU restatement oracle/ (OSQP-0.6-style, not OSQP itself), gcc -O3 -march=native, OpenMP one instance "
+                       "per thread" % (Bc, steps, tot),
+             "mpc_s": t_mpc, "wbc_s": t_wbc}, outs)
+
+
+def accuracy_vs_oracle(synth, ref_out, Bc, N, N_gait, gaits, steps, dev):
+    """The metric's accuracy half: the HIP path on the cpu_baseline sample (same seeds, same sequence, every step incl.
+    the set-up call), compared with the oracle's outputs.  north_star's bar: 1e-4 relative."""
+    import torch
+
+    import qrw_hip
+
+    sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps + 1)
+    eng = qrw_hip.Batch(Bc, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    tau_abs = tau_ref_max = f_abs = f_ref_max = x_abs = x_ref_max = 0.0
+    for s in range(steps + 1):
+        d = sb.step(s)
+        t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
+             ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")}
+        o = eng.mpc_solve(t["xref"], t["fsteps"], s)
+        w = eng.wbc_compute(t["q"], t["dq"], o[:, 12:, 0].contiguous(), t["contacts"], t["pgoals"], t["vgoals"], t["agoals"])
+        r, tau, f = ref_out[s]
+        og, tg, fg = o.cpu().numpy(), w["tau_ff"].cpu().numpy(), w["f_with_delta"].cpu().numpy()
+        tau_abs, tau_ref_max = max(tau_abs, np.abs(tg - tau).max()), max(tau_ref_max, np.abs(tau).max())
+        f_abs, f_ref_max = max(f_abs, np.abs(fg - f).max()), max(f_ref_max, np.abs(f).max())
+        x_abs, x_ref_max = max(x_abs, np.abs(og - r).max()), max(x_ref_max, np.abs(r).max())
+    eng.close()
+    return {"torque_max_abs_err": float(tau_abs), "torque_max_rel_err": float(tau_abs / tau_ref_max),
+            "force_max_rel_err": float(f_abs / f_ref_max), "mpc_result_max_rel_err": float(x_abs / x_ref_max),
+            "torque_scale_Nm": float(tau_ref_max), "tolerance_rel": 1e-4,
+            "within_tolerance": bool(max(tau_abs / tau_ref_max, f_abs / f_ref_max, x_abs / x_ref_max) < 1e-4),
+            "sample": "%d instances x %d control steps, GPU (strict build) vs CPU oracle (-O3 -march=native build used for the "
+                      "timing), max over all instances and steps; relative = max abs error / max abs reference" % (Bc, steps + 1)}
 
 
 if __name__ == "__main__":

@@ -76,6 +76,11 @@ int qrw_mpc_solve_host(qrw_handle h, const double *h_xref, const double *h_fstep
  * h_gait [N_gait][4], h_Sgait [12 N] */
 int qrw_mpc_get_gait(qrw_handle h, int32_t b, double *h_gait, double *h_Sgait);
 
+/* Device-to-device copy of the last solve's ADMM iteration counts (int32 [B]) on `stream`: lets a caller keep per-launch
+ * work statistics in HBM without a host round trip inside a timed region (bench.py's roofline accounting).  No reference
+ * counterpart: OSQP's info->iter is never read by the reference (src/MPC.cpp:558). */
+int qrw_mpc_copy_iters(qrw_handle h, int32_t *d_iters, void *stream);
+
 /* Per-instance solver statistics of the last qrw_mpc_solve (host arrays of B, any may be NULL).
  * The reference never inspects them (OSQP status ignored); exposed so the silent
  * pass-through can be observed (SURVEY.md §8(b) error convention). */
@@ -202,6 +207,13 @@ int qrw_controller_wbc_inputs(qrw_handle h, const double *d_x_f_mpc, const doubl
 int qrw_controller_result(qrw_handle h, const double *d_tau_ff, const double *d_qdes, const double *d_vdes,
                           const double *d_q_filt, const double *d_v_secu, double *d_result, int32_t *d_error_flag,
                           void *stream);
+
+/* Bookkeeping of MPC_Wrapper.solve on the result the loop currently reads (scripts/MPC_Wrapper.py:89-102; observable in
+ * the reference's asynchronous mode only, where get_latest_result keeps returning it until the child process delivers):
+ * rows 12..23 of d_x_f_mpc [B][24][N] are rolled one column to the left (np.roll, the first column wraps to the end) and,
+ * when the last non-zero row of d_gait [B][N_gait][4] differs from row 0, the last column becomes m g / n_contacts
+ * (mass 2.5) on that row's stance feet.  The caller applies it when k > 2 (:89), as the reference does. */
+int qrw_mpc_result_shift(qrw_handle h, const double *d_gait, double *d_x_f_mpc, void *stream);
 
 /* Fused forms of the above, one launch each, for the device-resident control loop (same arithmetic):
  * qrw_control_pre = qrw_controller_update_state + qrw_planner_step (fed with its q, h_v, v_ref) and, when d_x_f_mpc is

@@ -69,10 +69,15 @@ typedef struct {
     }                                                                                           \
   }
 
-static const qrw_solo12_model QRW_SOLO12_MODEL = {
-    {1.16115091, {0.0, 0.0, 0.0}, {0.00578574, 0.0, 0.0, 0.01938108, 0.0, 0.02476124}},
-    {QRW_LEG(1.0, 1.0), QRW_LEG(1.0, -1.0), QRW_LEG(-1.0, 1.0), QRW_LEG(-1.0, -1.0)},
-    9.81};
+/* The initialiser as a macro so that device code can make its own constant copy of the SAME numbers
+ * (csrc/wbc_kernel.hip: `constexpr qrw_solo12_model ... = QRW_SOLO12_MODEL_INIT`). */
+#define QRW_SOLO12_MODEL_INIT                                                                \
+  {                                                                                          \
+    {1.16115091, {0.0, 0.0, 0.0}, {0.00578574, 0.0, 0.0, 0.01938108, 0.0, 0.02476124}},      \
+        {QRW_LEG(1.0, 1.0), QRW_LEG(1.0, -1.0), QRW_LEG(-1.0, 1.0), QRW_LEG(-1.0, -1.0)}, 9.81 \
+  }
+
+static const qrw_solo12_model QRW_SOLO12_MODEL = QRW_SOLO12_MODEL_INIT;
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,11 @@ class Controller_batch:
         i = n % 3
         if self._adopted == i and self._pending:  # the loop still reads the buffer this solve will write: catch up
             self._adopt(self._pending[-1][0], wait=True)
+        if n >= 3:
+            # solve n-3 read these snapshot buffers and wrote this output buffer: it must have finished before the loop
+            # stream overwrites them (free-running start-up, before anything has been adopted; a no-op afterwards).
+            # This also bounds the backlog on the MPC stream to three solves.
+            self._s_loop.torch.wait_event(self._ev_done[i])
         xs, fs = self._snap[i]
         xs.copy_(plan["xref"])
         fs.copy_(plan["fsteps"])
@@ -102,6 +107,10 @@ class Controller_batch:
             self._ev_done[i].record(self._s_mpc.torch)
         self._pending.append((n, k))
         self._n_issued = n + 1
+        if k > 2:
+            # scripts/MPC_Wrapper.py:89-102: the result the loop keeps reading until the new one arrives is shifted one
+            # horizon step (its first column is the force the WBC applies); before any adoption that is the default result
+            self._b.mpc_result_shift(plan["gait"], self._mpc_out if self._mpc_out is not None else self._mpc_default)
 
     def _adopt(self, n, wait):
         i = n % 3

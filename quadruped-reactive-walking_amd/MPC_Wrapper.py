@@ -20,34 +20,24 @@ import qrw_hip
 
 
 def quaternionToRPY(quat):
-    """Quaternion (x, y, z, w) to roll-pitch-yaw (3 x 1) — scripts/utils_mpc.py:37-71."""
-    qx, qy, qz, qw = [float(v) for v in np.asarray(quat).ravel()[:4]]
-    rotateXa0 = 2.0 * (qy * qz + qw * qx)
-    rotateXa1 = qw * qw - qx * qx - qy * qy + qz * qz
-    rotateX = 0.0
-    if (rotateXa0 != 0.0) and (rotateXa1 != 0.0):
-        rotateX = np.arctan2(rotateXa0, rotateXa1)
-    rotateYa0 = -2.0 * (qx * qz - qw * qy)
-    if rotateYa0 >= 1.0:
-        rotateY = np.pi / 2.0
-    elif rotateYa0 <= -1.0:
-        rotateY = -np.pi / 2.0
-    else:
-        rotateY = np.arcsin(rotateYa0)
-    rotateZa0 = 2.0 * (qx * qy + qw * qz)
-    rotateZa1 = qw * qw + qx * qx - qy * qy - qz * qz
-    rotateZ = 0.0
-    if (rotateZa0 != 0.0) and (rotateZa1 != 0.0):
-        rotateZ = np.arctan2(rotateZa0, rotateZa1)
-    return np.array([[rotateX], [rotateY], [rotateZ]])
+    """Roll-pitch-yaw (3 x 1, ZYX convention) of a quaternion given as (x, y, z, w).
 
+    Same contract as the helper the reference's wrapper uses for its first-iteration default result
+    (scripts/utils_mpc.py:37-71, called at scripts/MPC_Wrapper.py:68), including its one quirk: roll and yaw are
+    left at 0 whenever either argument of their arctan2 is exactly 0."""
+    x, y, z, w = (float(v) for v in np.asarray(quat, dtype=np.float64).ravel()[:4])
+    # the five entries of the (unnormalised) rotation matrix R(q) that the ZYX angles are read from
+    r11 = w * w + x * x - y * y - z * z
+    r21 = 2.0 * (x * y + w * z)
+    r31 = 2.0 * (x * z - w * y)
+    r32 = 2.0 * (y * z + w * x)
+    r33 = w * w - x * x - y * y + z * z
 
-class Dummy:
-    """Dummy class to store variables"""
+    def angle(num, den):
+        return float(np.arctan2(num, den)) if (num != 0.0 and den != 0.0) else 0.0
 
-    def __init__(self):
-        self.xref = None  # Desired trajectory
-        self.fsteps = None  # Desired location of footsteps
+    pitch = float(np.arcsin(min(1.0, max(-1.0, -r31))))  # saturates at +-pi/2 at the gimbal lock
+    return np.array([[angle(r32, r33)], [pitch], [angle(r21, r11)]])
 
 
 class MPC_Wrapper:

@@ -171,5 +171,39 @@ __device__ __forceinline__ void result(const ControllerArgs& a, int b) {
   if (a.iout) a.iout[b] = err;
 }
 
+// MPC_Wrapper.solve bookkeeping on the result the control loop currently reads (scripts/MPC_Wrapper.py:89-102), in the
+// reference only observable in the asynchronous mode: past the first iterations the force rows 12..23 are rolled one
+// horizon step to the left (np.roll: the first column wraps to the end), and when the last gait row before the first
+// all-zero one is in another phase than row 0 the freed last column gets m g / n_contacts (mass 2.5, :98) on its
+// stance feet.  in0 = gait [B][N_gait][4] (doubles, FootstepPlanner / Gait layout), out0 = x_f_mpc [B][24][N] in place.
+__device__ __forceinline__ void mpc_result_shift(const ControllerArgs& a, int b) {
+  const int N = a.n_steps, Ng = a.n_gait;
+  double* xf = a.out0 + (size_t)b * 24 * N;
+  const double* g = a.in0 + (size_t)b * Ng * 4;
+  const int r_end = (12 + N < 24) ? 12 + N : 24;  // the reference slices rows 12:(12+n_steps) of the 24-row array (:90)
+  for (int r = 12; r < r_end; r++) {
+    const double first = xf[r * N];
+    for (int c = 0; c + 1 < N; c++) xf[r * N + c] = xf[r * N + c + 1];
+    xf[r * N + N - 1] = first;
+  }
+  int pt = 0;
+  while (pt < Ng && (g[pt * 4] != 0.0 || g[pt * 4 + 1] != 0.0 || g[pt * 4 + 2] != 0.0 || g[pt * 4 + 3] != 0.0)) pt++;
+  const int last = pt > 0 ? pt - 1 : Ng - 1;  // gait[pt-1] with Python's negative index when row 0 is already zero
+  bool differs = false;
+  double n_ctc = 0.0;
+  for (int i = 0; i < 4; i++) {
+    differs = differs || (g[i] != g[last * 4 + i]);
+    n_ctc += g[last * 4 + i];
+  }
+  if (differs) {
+    const double F = 9.81 * 2.5 / n_ctc;
+    for (int i = 0; i < 4; i++) {
+      xf[(12 + 3 * i) * N + N - 1] = 0.0;
+      xf[(13 + 3 * i) * N + N - 1] = 0.0;
+      xf[(14 + 3 * i) * N + N - 1] = (g[last * 4 + i] == 1.0) ? F : 0.0;
+    }
+  }
+}
+
 }  // namespace glue
 }  // namespace qrw

@@ -4,6 +4,7 @@
 //   updateState                :381-426  perfect x/y/yaw integration, horizontal-frame velocity, oRh / oTh
 //   WBC target assembly        :258-296  x_f_wbc, q_wbc, b_v, foot commands in the base frame
 //   result + security_check    :306-310, :341-365
+//   (+ the force-row shift of MPC_Wrapper.solve, scripts/MPC_Wrapper.py:89-102, used by the asynchronous MPC mode)
 // so that a whole control iteration (planners -> MPC -> WBC -> PD targets) stays in HBM.
 // One thread per instance; persistent state item-major cs[item][instance].
 #include <hip/hip_runtime.h>
@@ -28,6 +29,8 @@ __global__ __launch_bounds__(64) void controller_kernel(ControllerArgs a) {
     glue::wbc_inputs(a, b);
   } else if (a.mode == kCtrlResult) {
     glue::result(a, b);
+  } else if (a.mode == kCtrlMpcShift) {
+    glue::mpc_result_shift(a, b);
   }
 }
 

@@ -61,6 +61,20 @@ struct qrw_handle_s {
 
 extern "C" const char* qrw_last_error(void) { return g_err.c_str(); }
 
+// Every entry point works on the device its handle was created on and leaves the caller's current device alone.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 static void base_inertia_diag(double Y[6]) {
   // diag of crba(q_neutral)[:6,:6] (scripts/QP_WBC.py:89-93): total mass and the composite
   // rotational inertia about the base origin with every joint at zero (all link frames axis-aligned).
@@ -106,7 +120,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(-2, "qrw_create: no HIP device (this library has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(-2, "qrw_create: bad device ordinal");
-  HIP_OK(hipSetDevice(cfg->device), "hipSetDevice");
+  DeviceScope dev_scope__(cfg->device);
   qrw_handle h = new qrw_handle_s();
   h->cfg = *cfg;
   const size_t B = (size_t)cfg->batch;
@@ -150,6 +164,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
 
 extern "C" int qrw_destroy(qrw_handle h) {
   if (!h) return 0;
+  DeviceScope dev_scope__(h->cfg.device);
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_ema); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
@@ -168,6 +183,7 @@ extern "C" int64_t qrw_state_bytes(qrw_handle h) {
 extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d_fsteps, const int32_t* d_num_iter,
                              int32_t num_iter_scalar, double* d_out, void* stream) {
   if (!h || !d_xref || !d_fsteps || !d_out) return fail(-1, "qrw_mpc_solve: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::MpcArgs a;
   a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
   a.xref = d_xref; a.fsteps = d_fsteps; a.num_iter = d_num_iter; a.num_iter_scalar = num_iter_scalar;
@@ -189,6 +205,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
 extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const double* h_fsteps, const int32_t* h_num_iter,
                                   int32_t num_iter_scalar, double* h_out) {
   if (!h || !h_xref || !h_fsteps || !h_out) return fail(-1, "qrw_mpc_solve_host: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   double* dx = h->stage;
   double* df = dx + B * 12 * (N + 1);
@@ -202,8 +219,17 @@ extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const doub
   return 0;
 }
 
+extern "C" int qrw_mpc_copy_iters(qrw_handle h, int32_t* d_iters, void* stream) {
+  if (!h || !d_iters) return fail(-1, "qrw_mpc_copy_iters: null argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  HIP_OK(hipMemcpyAsync(d_iters, h->mpc_iters, (size_t)h->cfg.batch * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream),
+         "qrw_mpc_copy_iters");
+  return 0;
+}
+
 extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double* h_Sgait) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_gait: bad argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const int N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   HIP_OK(hipDeviceSynchronize(), "sync");
   if (h_gait) {
@@ -226,6 +252,7 @@ extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double*
 extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_status, double* h_rho, double* h_pri_res,
                                  double* h_dua_res) {
   if (!h) return fail(-1, "qrw_mpc_get_stats: null handle");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   HIP_OK(hipDeviceSynchronize(), "sync");
   if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
@@ -239,6 +266,7 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
 extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h_z, double* h_y, double* h_D,
                                  double* h_E, double* h_c) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_state: bad argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const int N = h->cfg.n_steps;
   const int T = qrw::mpc_threads(N);
   std::vector<double> s((size_t)qrw::kMpcStItems * T);
@@ -283,6 +311,7 @@ extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_
                                double* d_f_with_delta, double* d_ddq_res, double* d_feet, void* stream) {
   if (!h || !d_q || !d_dq || !d_f_cmd || !d_contacts || !d_pgoals || !d_vgoals || !d_agoals)
     return fail(-1, "qrw_wbc_compute: null input");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::WbcArgs a;
   wbc_common(h, a);
   a.mode = 0;
@@ -302,6 +331,7 @@ extern "C" int qrw_wbc_compute_result(qrw_handle h, const double* d_q, const dou
   if (!h || !d_q || !d_dq || !d_f_cmd || !d_contacts || !d_pgoals || !d_vgoals || !d_agoals || !d_q_filt || !d_v_secu ||
       !d_result)
     return fail(-1, "qrw_wbc_compute_result: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::WbcArgs a;
   wbc_common(h, a);
   a.mode = 0;
@@ -344,6 +374,7 @@ extern "C" int qrw_wbc_compute_host(qrw_handle h, const double* h_q, const doubl
                                     const double* h_agoals, double* h_tau_ff, double* h_qdes, double* h_vdes,
                                     double* h_f_with_delta, double* h_ddq_res, double* h_feet) {
   if (!h) return fail(-1, "qrw_wbc_compute_host: null handle");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   Stager s(h);
   double *q = s.in(h_q, B * 19), *dq = s.in(h_dq, B * 18), *f = s.in(h_f_cmd, B * 12), *c = s.in(h_contacts, B * 4);
@@ -363,6 +394,7 @@ extern "C" int qrw_wbc_compute_host(qrw_handle h, const double* h_q, const doubl
 extern "C" int qrw_wbc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_status, double* h_rho,
                                  double* h_k_since_contact) {
   if (!h) return fail(-1, "qrw_wbc_get_stats: null handle");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   HIP_OK(hipDeviceSynchronize(), "sync");
   if (h_iters) HIP_OK(hipMemcpy(h_iters, h->wbc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
@@ -382,6 +414,7 @@ extern "C" int qrw_wbc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
 extern "C" int qrw_fixed_feet_host(qrw_handle h, const double* h_q12, const double* h_dq12, double* h_posf, double* h_vf,
                                    double* h_wf, double* h_af, double* h_Jf) {
   if (!h || !h_q12 || !h_dq12) return fail(-1, "qrw_fixed_feet_host: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   Stager s(h);
   qrw::WbcArgs a;
@@ -403,6 +436,7 @@ extern "C" int qrw_invkin_host(qrw_handle h, const double* h_contacts, const dou
                                const double* h_af, const double* h_Jf, double* h_ddq, double* h_dq_cmd,
                                double* h_q_step) {
   if (!h) return fail(-1, "qrw_invkin_host: null handle");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   Stager s(h);
   qrw::WbcArgs a;
@@ -423,6 +457,7 @@ extern "C" int qrw_invkin_host(qrw_handle h, const double* h_contacts, const dou
 extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_Jc, const double* h_f_cmd,
                               const double* h_RNEA, double* h_f_res, double* h_ddq_res, double* h_H) {
   if (!h || !h_M || !h_Jc || !h_f_cmd || !h_RNEA) return fail(-1, "qrw_qpwbc_host: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   Stager s(h);
   qrw::WbcArgs a;
@@ -440,6 +475,7 @@ extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_J
 
 extern "C" int qrw_get_base_inertia_diag(qrw_handle h, double* h_Y6) {
   if (!h || !h_Y6) return fail(-1, "qrw_get_base_inertia_diag: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   for (int i = 0; i < 6; i++) h_Y6[i] = h->Y[i];
   return 0;
 }
@@ -453,6 +489,7 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
 // Diagnostic (profiling builds only, -DQRW_PROFILE_PHASES): per-instance shader-clock totals of the MPC kernel phases.
 extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] */) {
   if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   HIP_OK(hipDeviceSynchronize(), "sync");
   HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * 10 * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
   return 0;
@@ -472,6 +509,7 @@ static void planner_common(qrw_handle h, qrw::PlannerArgs& a) {
 
 extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void* stream) {
   if (!h || !pc) return fail(-1, "qrw_planner_init: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   if (pc->k_mpc < 1) return fail(-1, "qrw_planner_init: k_mpc must be >= 1");
   if (h->cfg.N_gait > 63) return fail(-1, "qrw_planner_init: N_gait must be <= 63 (gait matrices are 64-bit column masks)");
   // Gait::initialize throws when the matrices are too small (src/Gait.cpp:30-31)
@@ -492,6 +530,7 @@ extern "C" int qrw_planner_step(qrw_handle h, int32_t k, const double* d_q7, int
                                 double* d_fsteps, double* d_gait, double* d_target, double* d_feet_pva,
                                 double* d_contacts, void* stream) {
   if (!h || !h->plan_ready) return fail(-1, "qrw_planner_step: planner not initialised");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   if (!d_q7 || !d_hv || !d_vref) return fail(-1, "qrw_planner_step: null input");
   if (q_ld < 7) return fail(-1, "qrw_planner_step: q_ld must be at least 7");
   qrw::PlannerArgs a;
@@ -512,6 +551,7 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
                                      const double* h_target_in, double z_average, double* h_xref, double* h_fsteps,
                                      double* h_gait, double* h_target, double* h_feet_pva) {
   if (!h || !h->plan_ready) return fail(-1, "qrw_planner_call_host: planner not initialised");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   Stager s(h);
   qrw::PlannerArgs a;
@@ -538,6 +578,7 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
 
 extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double* h_out) {
   if (!h || !h_out || b < 0 || b >= h->cfg.batch || count < 1) return fail(-1, "qrw_planner_get_host: bad argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const int off = qrw::planner_item_offset(h->cfg.N_gait, which);
   const size_t B = h->cfg.batch;
   HIP_OK(hipDeviceSynchronize(), "sync");
@@ -563,10 +604,21 @@ extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int3
 static void ctrl_common(qrw_handle h, qrw::ControllerArgs& a, int mode) {
   memset(&a, 0, sizeof(a));
   a.B = h->cfg.batch; a.n_steps = h->cfg.n_steps; a.mode = mode; a.dt_wbc = h->cfg.dt_wbc; a.h_ref = h->pcfg.h_ref;
+  a.n_gait = h->cfg.N_gait;
   a.cs = h->ctrl_st;
+}
+extern "C" int qrw_mpc_result_shift(qrw_handle h, const double* d_gait, double* d_x_f_mpc, void* stream) {
+  if (!h || !d_gait || !d_x_f_mpc) return fail(-1, "qrw_mpc_result_shift: null argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  qrw::ControllerArgs a;
+  ctrl_common(h, a, qrw::kCtrlMpcShift);
+  a.in0 = d_gait;
+  a.out0 = d_x_f_mpc;
+  return qrw::controller_launch(a, (hipStream_t)stream) ? fail(-11, "qrw_mpc_result_shift: launch failed", hipGetLastError()) : 0;
 }
 extern "C" int qrw_controller_init(qrw_handle h, const double* d_q_init12, double h_ref, void* stream) {
   if (!h) return fail(-1, "qrw_controller_init: null handle");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   h->pcfg.h_ref = h_ref;
   qrw::ControllerArgs a;
   ctrl_common(h, a, qrw::kCtrlInit);
@@ -578,6 +630,7 @@ extern "C" int qrw_controller_update_state(qrw_handle h, const double* d_joy_vre
                                            double* d_hv, double* d_vref, double* d_oRh_oTh, void* stream) {
   if (!h || !d_joy_vref || !d_q_filt || !d_v_filt || !d_rpy || !d_q || !d_v || !d_hv)
     return fail(-1, "qrw_controller_update_state: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::ControllerArgs a;
   ctrl_common(h, a, qrw::kCtrlUpdateState);
   a.in0 = d_joy_vref; a.in1 = d_q_filt; a.in2 = d_v_filt; a.in3 = d_rpy;
@@ -589,6 +642,7 @@ extern "C" int qrw_controller_wbc_inputs(qrw_handle h, const double* d_x_f_mpc, 
                                          double* d_b_v, double* d_f_cmd, double* d_feet_cmd, void* stream) {
   if (!h || !d_x_f_mpc || !d_xref || !d_feet_pva || !d_v || !d_q_wbc || !d_b_v || !d_feet_cmd)
     return fail(-1, "qrw_controller_wbc_inputs: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::ControllerArgs a;
   ctrl_common(h, a, qrw::kCtrlWbcInputs);
   a.in0 = d_x_f_mpc; a.in1 = d_xref; a.in2 = d_feet_pva; a.in3 = d_v;
@@ -600,6 +654,7 @@ extern "C" int qrw_controller_result(qrw_handle h, const double* d_tau_ff, const
                                      int32_t* d_error_flag, void* stream) {
   if (!h || !d_tau_ff || !d_qdes || !d_vdes || !d_q_filt || !d_v_secu || !d_result)
     return fail(-1, "qrw_controller_result: null argument");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::ControllerArgs a;
   ctrl_common(h, a, qrw::kCtrlResult);
   a.in0 = d_tau_ff; a.in1 = d_qdes; a.in2 = d_vdes; a.in3 = d_q_filt; a.in4 = d_v_secu;
@@ -618,8 +673,10 @@ extern "C" int qrw_device_cu_count(int32_t device, int32_t* n_cus) {
 }
 extern "C" int qrw_stream_create(int32_t device, int32_t first_cu, int32_t n_cus, void** stream) {
   if (!stream) return fail(-1, "qrw_stream_create: null argument");
-  hipError_t e = hipSetDevice(device);
-  if (e != hipSuccess) return fail(-10, "qrw_stream_create: hipSetDevice failed", e);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(-2, "qrw_stream_create: bad device ordinal");
+  DeviceScope dev_scope__(device);
+  hipError_t e = hipSuccess;
   hipStream_t s = nullptr;
   if (n_cus <= 0) {
     e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
@@ -651,6 +708,7 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
                                double* d_feet_pva, double* d_contacts, double* d_x_f_wbc, double* d_q_wbc, double* d_b_v,
                                double* d_f_cmd, double* d_feet_cmd, void* stream) {
   if (!h || !h->plan_ready) return fail(-1, "qrw_control_pre: planner not initialised");
+  DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   if (!d_joy_vref || !d_q_filt || !d_v_filt || !d_rpy || !d_q || !d_v || !d_hv || !d_vref || !d_xref || !d_feet_pva)
     return fail(-1, "qrw_control_pre: null argument");
   if (d_x_f_mpc && (!d_q_wbc || !d_b_v || !d_feet_cmd)) return fail(-1, "qrw_control_pre: null WBC target output");

@@ -115,10 +115,10 @@ struct PlannerArgs {
 int planner_state_items(int N_gait);
 
 // ---- controller glue (controller_kernel.hip)
-enum ControllerMode { kCtrlInit = 1, kCtrlUpdateState = 2, kCtrlWbcInputs = 3, kCtrlResult = 4 };
+enum ControllerMode { kCtrlInit = 1, kCtrlUpdateState = 2, kCtrlWbcInputs = 3, kCtrlResult = 4, kCtrlMpcShift = 5 };
 constexpr int kCtrlStItems = 58;
 struct ControllerArgs {
-  int B, n_steps, mode;
+  int B, n_steps, mode, n_gait;
   double dt_wbc, h_ref;
   const double *in0, *in1, *in2, *in3, *in4;
   double *out0, *out1, *out2, *out3, *out4;

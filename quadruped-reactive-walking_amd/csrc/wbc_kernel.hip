@@ -52,32 +52,59 @@ __device__ __forceinline__ V3 mulT(const M3& m, V3 v) {
 __device__ __forceinline__ V3 rotx(double c, double s, V3 v) { return mk(v.x, c * v.y - s * v.z, s * v.y + c * v.z); }
 __device__ __forceinline__ V3 roty(double c, double s, V3 v) { return mk(c * v.x + s * v.z, v.y, -s * v.x + c * v.z); }
 
-// Model constants of one leg (device copy of include/qrw_solo12_model.h)
+// Model constants of one leg.  The numbers come from include/qrw_solo12_model.h (the ONE data file):
+// the kernel takes the FL leg of a compile-time copy of that initialiser as immediates and applies the mirror signs of
+// the leg it works on; a static_assert proves that the other three legs of the data file ARE those mirror images, so
+// a model file that breaks the symmetry cannot be compiled into a kernel that silently ignores it.
 struct LegC {
   V3 haa, hfe, kfe, foot;
   double m[4];
   V3 com[4];
   double I[4][6];
 };
+constexpr qrw_solo12_model kModel = QRW_SOLO12_MODEL_INIT;
+// sign of entry e of (com | inertia) of link `link` (0 shoulder, 1 upper, 2 lower, 3 foot) for mirror signs (sx, sy)
+constexpr double mirror_sign(int link, bool inertia, int e, double sx, double sy) {
+  if (!inertia) return (e == 0 && link == 0) ? sx : (e == 1 && link != 3) ? sy : 1.0;
+  if (link == 0) return e == 1 ? sx * sy : 1.0;            // shoulder: ixy
+  if (link == 1 || link == 2) return e == 4 ? sy : 1.0;    // upper / lower leg: iyz
+  return 1.0;
+}
+constexpr bool same(double a, double b) { return a == b; }
+constexpr bool link_is_mirror(const qrw_link_inertial& a, const qrw_link_inertial& fl, int link, double sx, double sy) {
+  bool ok = same(a.mass, fl.mass);
+  for (int e = 0; e < 3; e++) ok = ok && same(a.com[e], mirror_sign(link, false, e, sx, sy) * fl.com[e]);
+  for (int e = 0; e < 6; e++) ok = ok && same(a.inertia[e], mirror_sign(link, true, e, sx, sy) * fl.inertia[e]);
+  return ok;
+}
+constexpr bool leg_is_mirror(const qrw_leg_model& a, const qrw_leg_model& fl, double sx, double sy) {
+  bool ok = same(a.haa_xyz[0], sx * fl.haa_xyz[0]) && same(a.haa_xyz[1], sy * fl.haa_xyz[1]) && same(a.haa_xyz[2], fl.haa_xyz[2]);
+  const double* o[3] = {a.hfe_xyz, a.kfe_xyz, a.foot_xyz};
+  const double* f[3] = {fl.hfe_xyz, fl.kfe_xyz, fl.foot_xyz};
+  for (int i = 0; i < 3; i++) ok = ok && same(o[i][0], f[i][0]) && same(o[i][1], sy * f[i][1]) && same(o[i][2], f[i][2]);
+  return ok && link_is_mirror(a.shoulder, fl.shoulder, 0, sx, sy) && link_is_mirror(a.upper, fl.upper, 1, sx, sy) &&
+         link_is_mirror(a.lower, fl.lower, 2, sx, sy) && link_is_mirror(a.foot, fl.foot, 3, sx, sy);
+}
+static_assert(leg_is_mirror(kModel.leg[0], kModel.leg[0], 1.0, 1.0) && leg_is_mirror(kModel.leg[1], kModel.leg[0], 1.0, -1.0) &&
+                  leg_is_mirror(kModel.leg[2], kModel.leg[0], -1.0, 1.0) && leg_is_mirror(kModel.leg[3], kModel.leg[0], -1.0, -1.0),
+              "include/qrw_solo12_model.h: legs FR/HL/HR are not the mirror images of FL that wbc_kernel assumes");
+
 __device__ __forceinline__ LegC leg_consts(int j) {
   LegC L;
   const double sx = (j < 2) ? 1.0 : -1.0, sy = (j & 1) ? -1.0 : 1.0;
-  // FL entries of QRW_SOLO12_MODEL with the mirror signs of QRW_LEG(sx, sy)
-  L.haa = mk(sx * 0.1946, sy * 0.0875, 0.0);
-  L.hfe = mk(0.0, sy * 0.014, 0.0);
-  L.kfe = mk(0.0, sy * 0.03745, -0.16);
-  L.foot = mk(0.0, sy * 0.008, -0.16);
-  L.m[0] = 0.14853845; L.m[1] = 0.14853845; L.m[2] = 0.03070001; L.m[3] = 0.00693606;
-  L.com[0] = mk(sx * -0.078707, sy * 0.01, 0.0);
-  L.com[1] = mk(0.00001377, sy * 0.01935853, -0.07870700);
-  L.com[2] = mk(0.0, sy * 0.00787644, -0.08928215);
-  L.com[3] = mk(0.0, 0.0, 0.00035767);
-  const double I0[6] = {0.00003024, sx * sy * 0.00004671, 0.0, 0.00041193, 0.0, 0.00041107};
-  const double I1[6] = {0.00041107, 0.0, 0.00000009, 0.00041193, sy * 0.00004671, 0.00003024};
-  const double I2[6] = {0.00012024, 0.0, 0.0, 0.00012029, sy * 0.00000305, 0.00000216};
-  const double I3[6] = {0.00000057, 0.0, 0.0, 0.00000084, 0.0, 0.00000053};
+  constexpr qrw_leg_model FL = kModel.leg[0];
+  L.haa = mk(sx * FL.haa_xyz[0], sy * FL.haa_xyz[1], FL.haa_xyz[2]);
+  L.hfe = mk(FL.hfe_xyz[0], sy * FL.hfe_xyz[1], FL.hfe_xyz[2]);
+  L.kfe = mk(FL.kfe_xyz[0], sy * FL.kfe_xyz[1], FL.kfe_xyz[2]);
+  L.foot = mk(FL.foot_xyz[0], sy * FL.foot_xyz[1], FL.foot_xyz[2]);
+  constexpr qrw_link_inertial LK[4] = {FL.shoulder, FL.upper, FL.lower, FL.foot};
 #pragma unroll
-  for (int e = 0; e < 6; e++) { L.I[0][e] = I0[e]; L.I[1][e] = I1[e]; L.I[2][e] = I2[e]; L.I[3][e] = I3[e]; }
+  for (int l = 0; l < 4; l++) {
+    L.m[l] = LK[l].mass;
+    L.com[l] = mk(mirror_sign(l, false, 0, sx, sy) * LK[l].com[0], mirror_sign(l, false, 1, sx, sy) * LK[l].com[1], LK[l].com[2]);
+#pragma unroll
+    for (int e = 0; e < 6; e++) L.I[l][e] = mirror_sign(l, true, e, sx, sy) * LK[l].inertia[e];
+  }
   return L;
 }
 

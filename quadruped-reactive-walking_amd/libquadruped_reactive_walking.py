@@ -81,7 +81,15 @@ class QPWBC:
         self._H = np.zeros((12, 12))
 
     def run(self, M, Jc, f_cmd, RNEA, k_contact):
-        f, d, H = self._b.qpwbc_host(np.asarray(M, dtype=np.float64)[None], np.asarray(Jc, dtype=np.float64)[None],
+        M = np.asarray(M, dtype=np.float64)
+        Y = M[:6, :6]
+        if np.any(Y - np.diag(np.diag(Y)) != 0.0):
+            # src/QPWBC.cpp:486 pseudo-inverts the full 6x6 block (include/qrw/InvKin.hpp:60-66, JacobiSVD); the kernel
+            # implements the case the reference's caller always produces — the block masked to its diagonal
+            # (scripts/QP_WBC.py:93) — and refuses anything else rather than silently using the diagonal only.
+            raise ValueError("QPWBC.run: M[:6,:6] must be diagonal (scripts/QP_WBC.py:93 masks it); the general "
+                             "pseudo-inverse of include/qrw/InvKin.hpp:60-66 is not implemented on the device")
+        f, d, H = self._b.qpwbc_host(M[None], np.asarray(Jc, dtype=np.float64)[None],
                                      np.asarray(f_cmd, dtype=np.float64).reshape(1, 12),
                                      np.asarray(RNEA, dtype=np.float64).reshape(1, 6))
         self._f_res, self._ddq_res, self._H = f[0], d[0], H[0]

@@ -46,6 +46,7 @@ SIGNATURES = {
     "qrw_mpc_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "qrw_mpc_solve_host": (C.c_int, [_vp, _dp, _dp, _ip, C.c_int32, _dp]),
     "qrw_mpc_get_gait": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
+    "qrw_mpc_copy_iters": (C.c_int, [_vp, _vp, _vp]),
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "qrw_controller_update_state": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_wbc_inputs": (C.c_int, [_vp] + [_vp] * 9 + [_vp]),
     "qrw_controller_result": (C.c_int, [_vp] + [_vp] * 7 + [_vp]),
+    "qrw_mpc_result_shift": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qrw_control_pre": (C.c_int, [_vp, C.c_int32] + [_vp] * 4 + [_vp, C.c_int32, _vp] + [_vp] * 16 + [_vp]),
     "qrw_wbc_compute_result": (C.c_int, [_vp] + [_vp] * 13 + [_vp] * 4 + [_vp]),
     "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
@@ -176,21 +178,22 @@ class Batch:
             pass
 
     # ------------------------------------------------ device-resident API (torch tensors)
-    @staticmethod
-    def _dev(t, shape):
+    def _dev(self, t, shape):
         import torch
 
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
             raise QrwError("expected a contiguous float64 CUDA tensor")
+        if t.device.index != self.device:
+            raise QrwError("tensor lives on cuda:%s, this handle on cuda:%d" % (t.device.index, self.device))
         if tuple(t.shape) != tuple(shape):
             raise QrwError("bad shape %s, expected %s" % (tuple(t.shape), tuple(shape)))
         return _vp(t.data_ptr())
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
+        """The caller's current stream ON THIS HANDLE'S DEVICE (not on whatever device is current)."""
         import torch
 
-        return _vp(torch.cuda.current_stream().cuda_stream)
+        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
 
     def mpc_solve(self, xref, fsteps, num_iter, out=None):
         """xref (B,12,N+1), fsteps (B,N_gait,12) CUDA float64; num_iter int or CUDA int32 (B,). Returns (B,24,N)."""
@@ -231,6 +234,16 @@ class Batch:
             self._dev(out["ddq_res"], (B, 6)), self._dev(out["feet"], (B, 3, 3, 4)), self._stream()),
             "qrw_wbc_compute")
         return out
+
+    def copy_mpc_iters(self, dst):
+        """Last solve's ADMM iteration counts -> CUDA int32 tensor (B,), device to device on the current stream."""
+        import torch
+
+        if not (isinstance(dst, torch.Tensor) and dst.is_cuda and dst.dtype == torch.int32 and dst.is_contiguous()
+                and tuple(dst.shape) == (self.B,) and dst.device.index == self.device):
+            raise QrwError("copy_mpc_iters: expected a contiguous CUDA int32 tensor of shape (%d,) on cuda:%d" % (self.B, self.device))
+        _check(self._lib.qrw_mpc_copy_iters(self._handle, _vp(dst.data_ptr()), self._stream()), "qrw_mpc_copy_iters")
+        return dst
 
     # ------------------------------------------------ host-buffer API (numpy)
     def mpc_solve_host(self, xref, fsteps, num_iter):
@@ -412,6 +425,13 @@ class Batch:
             self._dev(q_filt, (B, 19)), self._dev(v_secu, (B, 12)), self._dev(out["result"], (B, 5, 12)),
             _vp(out["error_flag"].data_ptr()), self._stream()), "qrw_controller_result")
         return out
+
+    def mpc_result_shift(self, gait, x_f_mpc):
+        """MPC_Wrapper.solve bookkeeping (scripts/MPC_Wrapper.py:89-102) in place on x_f_mpc (B,24,N); gait (B,N_gait,4)."""
+        _check(self._lib.qrw_mpc_result_shift(self._handle, self._dev(gait, (self.B, self.N_gait, 4)),
+                                              self._dev(x_f_mpc, (self.B, 24, self.N)), self._stream()),
+               "qrw_mpc_result_shift")
+        return x_f_mpc
 
     # ------------------------------------------------ fused control iteration (two launches + the MPC solve)
     def control_pre(self, k, joy_v_ref, q_filt, v_filt, rpy, code=0, x_f_mpc=None, out=None):

@@ -39,3 +39,69 @@ class ResultGatherer:
         if self.host_staged:
             local = local.cpu()
         return dist.all_gather_into_tensor(self.out, local, group=self.group, async_op=async_op)
+
+
+class TorqueGatherPipeline:
+    """BASELINE config 5's collective: every control step each rank all-gathers the joint torques of its shard
+    (12 f64 per instance) so that every rank holds all robots' torques — issued on a side stream right after the step's
+    WBC kernel and left in flight while the next step computes (one step deep, two result buffers).
+
+    RCCL path (backend nccl): the collective is enqueued behind an event of the producing stream; `wait_buffer_free`
+    makes the PRODUCING STREAM (not the host) wait for the gather that last read a buffer before it is overwritten.
+    Other backends (gloo rehearsals on a CPU or on a 1-GPU box) stage through the host with the same call sequence."""
+
+    def __init__(self, b_local, device, width=12, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.dev = torch.device(device)
+        self.on_gpu = self.dev.type == "cuda"
+        self.b_local, self.width = int(b_local), int(width)
+        out_dev = self.dev if self.nccl else torch.device("cpu")
+        self.out = [torch.empty((self.world * self.b_local, self.width), dtype=torch.float64, device=out_dev) for _ in range(2)]
+        self.side = torch.cuda.Stream(self.dev) if (self.on_gpu and self.nccl) else None
+        self.work = [None, None]
+        self.last = None
+
+    def issue(self, i, tau):
+        """Start the all-gather of this step's torques `tau` (b_local, width) into result buffer i."""
+        if self.nccl:
+            produced = torch.cuda.Event()
+            produced.record(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(produced)
+                self.work[i] = dist.all_gather_into_tensor(self.out[i], tau, group=self.group, async_op=True)
+        else:
+            local = tau.cpu() if self.on_gpu else tau.clone()
+            self.work[i] = dist.all_gather_into_tensor(self.out[i], local, group=self.group, async_op=True)
+        self.last = i
+
+    def wait_buffer_free(self, i):
+        """Before the producer overwrites the torque buffer that gather i read: order it behind that gather."""
+        w = self.work[i]
+        if w is not None:
+            w.wait()  # nccl: the current (producing) stream waits on the device; gloo: the host waits
+            self.work[i] = None
+
+    def drain(self):
+        for i in (0, 1):
+            self.wait_buffer_free(i)
+
+    def check_last(self, rank, world, local_tau):
+        """After drain(): the last gathered buffer holds this rank's own torques in its slot, is finite, and every
+        rank's slot sums to the checksum that rank computed of its own torques."""
+        if self.last is None:
+            return None
+        if self.on_gpu:
+            torch.cuda.synchronize(self.dev)
+        got = self.out[self.last]
+        mine = local_tau.to(got.device)
+        ok = bool(torch.equal(got[rank * self.b_local:(rank + 1) * self.b_local], mine)) and bool(torch.isfinite(got).all())
+        sums = torch.empty((world,), dtype=torch.float64, device=got.device)
+        dist.all_gather_into_tensor(sums, mine.sum().reshape(1), group=self.group)
+        block = got.reshape(world, -1).sum(dim=1)
+        ok = ok and bool(torch.allclose(block, sums, rtol=1e-12, atol=1e-9))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=got.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() == 1)

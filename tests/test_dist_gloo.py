@@ -76,3 +76,49 @@ def test_two_rank_shard_and_gather(oracle_mod, synth_mod):
         exp = np.concatenate([w.tau_ff, w.f_with_delta[:, 0], w.qdes[7:], w.vdes[6:, 0]])
         assert np.array_equal(gathered[b], exp), b
     assert gathered.shape == (total, 48)
+
+
+def _run_bench(extra_env, *flags, timeout=600):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(flags), env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_own_multi_rank_branch_two_ranks_gloo():
+    """`python bench.py --gpus 2` itself (its launcher, shard offsets, per-step torque all-gather pipeline, barrier +
+    max-over-ranks timing, second no-collective region, JSON assembly) on CPU tensors over gloo: QRW_BENCH_STUB=1
+    replaces the kernels — and only the kernels — by a deterministic stand-in, so the line's value means nothing."""
+    r, line = _run_bench({"QRW_BENCH_STUB": "1", "QRW_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "3", "--warmup", "2",
+                         "--batch", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["data"] == "stub" and line["scaling"] == "weak" and line["steps"] == 3
+    c = line["collective"]
+    assert c["ranks_seen"] == [0, 1] and c["gathered_block_check"] is True
+    assert c["bytes_per_rank_per_step"] == 8 * 12 * 8 and c["no_collective_steps_per_s"] > 0
+    assert line["value"] > 0 and abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_refuses_flag_launcher_mismatch():
+    r, line = _run_bench({"QRW_BENCH_STUB": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2",
+                         "--steps", "1", "--batch", "4")
+    assert r.returncode != 0 and line is None and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_real_kernels():
+    """The same branch with the real HIP path: two ranks sharing cuda:0 (QRW_SINGLE_DEVICE), gloo instead of RCCL
+    (two RCCL ranks cannot share one device); roofline figures come from rank 0's HIP events."""
+    r, line = _run_bench({"QRW_SINGLE_DEVICE": "1", "QRW_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "3",
+                         "--warmup", "2", "--batch", "64", "--no-cpu-baseline", "--no-secondary")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["data"] == "synthetic"
+    assert line["collective"]["ranks_seen"] == [0, 1] and line["collective"]["gathered_block_check"] is True
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["launches"] == 3

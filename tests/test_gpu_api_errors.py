@@ -71,3 +71,38 @@ def test_gait_initialize_raises_like_the_reference():
     g = lqrw.Gait()
     with pytest.raises(ValueError):  # src/Gait.cpp:30-31 throws std::invalid_argument
         g.initialize(0.02, 0.32, 0.32, 10)
+
+
+def test_qpwbc_refuses_a_non_diagonal_base_block(oracle_mod):
+    """src/QPWBC.cpp:486 pseudo-inverts the full 6x6 block (include/qrw/InvKin.hpp:60-66); the device path implements the
+    masked-diagonal case the reference's caller always produces (scripts/QP_WBC.py:93) and must refuse anything else."""
+    import libquadruped_reactive_walking as lrw
+
+    q = np.zeros(19)
+    q[6] = 1.0
+    q[7:] = [0.1, 0.7, -1.4, 0.0, 0.6, -1.3, 0.0, -0.7, 1.4, -0.1, -0.7, 1.4]
+    M = oracle_mod.crba(q)  # unmasked: the base block has off-diagonal terms
+    Jc = oracle_mod.feet_jacobians(q)
+    qp = lrw.QPWBC()
+    f_cmd = np.tile([0.0, 0.0, 6.0], 4)
+    RNEA = np.array([0.1, -0.2, 24.0, 0.05, 0.02, -0.01])
+    with pytest.raises(ValueError, match="diagonal"):
+        qp.run(M, Jc, f_cmd, RNEA, np.zeros(4))
+    Mm = M.copy()
+    Mm[:6, :6] *= np.eye(6)
+    assert qp.run(Mm, Jc, f_cmd, RNEA, np.zeros(4)) == 0
+
+
+def test_tensor_on_wrong_device_or_dtype_is_refused():
+    import torch
+
+    import qrw_hip
+
+    eng = qrw_hip.Batch(2, 16)
+    with pytest.raises(qrw_hip.QrwError):
+        eng.mpc_solve(torch.zeros((2, 12, 17), dtype=torch.float32, device="cuda"),
+                      torch.zeros((2, 20, 12), dtype=torch.float64, device="cuda"), 0)
+    with pytest.raises(qrw_hip.QrwError):
+        eng.copy_mpc_iters(torch.zeros((2,), dtype=torch.int64, device="cuda"))
+    # the handle's device survives a change of torch's current device only through the explicit device check
+    assert eng.device == 0 and torch.cuda.current_device() == 0

@@ -91,6 +91,20 @@ def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
     _closed_loop(oracle_mod, mode, fused, DEFAULT_CFG, 160 if (mode == "sync" and fused) else 45)
 
 
+def _shift_last_available(res, gait, n_steps):
+    """scripts/MPC_Wrapper.py:89-102 restated: roll the force rows one horizon step, refill the last column from the gait."""
+    res[12:(12 + n_steps), :] = np.roll(res[12:(12 + n_steps), :], -1, axis=1)
+    pt = 0
+    while np.any(gait[pt, :]):
+        pt += 1
+    if not np.array_equal(gait[0, :], gait[pt - 1, :]):
+        F = 9.81 * 2.5 / np.sum(gait[pt - 1, :])
+        res[12:, n_steps - 1] = 0.0
+        for i in range(4):
+            if gait[pt - 1, i] == 1:
+                res[12 + 3 * i + 2, n_steps - 1] = F
+
+
 def _closed_loop(oracle_mod, mode, fused, cfg, iters):
     """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
     made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state.  The
@@ -114,8 +128,10 @@ def _closed_loop(oracle_mod, mode, fused, cfg, iters):
     first[2, 0] = cfg["h_ref"]
     first[12:, 0] = [0.0, 0.0, 8.0] * 4
     not_first = [False] * B
-    issued = [[] for _ in range(B)]     # (iteration issued, result) per instance
-    adopted = [None] * B
+    issued = [[] for _ in range(B)]     # (iteration issued, result) per instance, not delivered yet
+    # scripts/MPC_Wrapper.py:70-71: what get_latest_result returns until a solve delivers (asynchronous mode) -- and what
+    # MPC_Wrapper.solve keeps shifting (:89-102)
+    last_available = [first.copy() for _ in range(B)]
     vref = rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0])
     qf = np.zeros((B, 19))
     qf[:, 2], qf[:, 6], qf[:, 7:] = cfg["h_ref"], 1.0, Q_INIT
@@ -138,11 +154,15 @@ def _closed_loop(oracle_mod, mode, fused, cfg, iters):
             if k % k_mpc == 0:
                 mpc[b].run(k, xref, fsteps)
                 issued[b].append((k, mpc[b].get_latest_result().copy()))
-            for k0, res_ in issued[b]:
-                if k >= k0 + lag:
-                    adopted[b] = res_
-            x_f_mpc = adopted[b] if (not_first[b] and adopted[b] is not None) else first
+                if mode != "sync" and k > 2:  # MPC_Wrapper.solve bookkeeping (:89-102), dead code in the synchronous mode
+                    _shift_last_available(last_available[b], cgait, n_steps)
+            if not_first[b]:  # get_latest_result (:106-126): the first call returns the default without looking
+                for k0, res_ in list(issued[b]):
+                    if k >= k0 + lag:
+                        last_available[b] = res_
+                        issued[b].remove((k0, res_))
             not_first[b] = True
+            x_f_mpc = last_available[b]
             pos, vel, acc, _, _ = plan[b].feet()
             xw, qw, bv = g.wbc_inputs(x_f_mpc, xref, oRh, oTh, pos, vel, acc)
             wbc[b].compute(qw, bv, xw[12:], cgait[0, :], g.feet_p_cmd, g.feet_v_cmd, g.feet_a_cmd)
@@ -182,3 +202,48 @@ def test_async_polling_mode_runs():
     assert int((ctl.error_flag != 0).sum().item()) == 0
     assert bool(torch.isfinite(ctl._res["result"]).all())
     ctl.stop_parallel_loop()
+
+
+def test_async_free_running_startup_keeps_snapshots_intact():
+    """Free-running asynchronous mode (mpc_lag=None) with a first solve that cannot finish in time (the MPC stream is
+    held back): solves 0..2 are still queued when solve 3 is issued, so the loop stream must wait for solve n-3 before
+    it overwrites that solve's snapshot / output buffers.  Each solve's inputs are cloned at issue and compared with
+    what the solve was handed; every solve must end `solved` and the loop must end on an adopted MPC result."""
+    import torch
+    from Controller import Controller_batch
+
+    B = 256
+    with torch.cuda.stream(torch.cuda.Stream()):
+        ctl = Controller_batch(B, Q_INIT, multiprocessing=True)
+        with torch.cuda.stream(ctl._s_mpc.torch):
+            torch.cuda._sleep(int(2.0e8))  # ~0.1 s at ~2 GHz: longer than the 50 loop iterations below take to issue
+        vref = _t(np.tile(np.array([0.3, 0.0, 0, 0, 0, 0.1]), (B, 1)))
+        qf = np.zeros((B, 19))
+        qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+        qf, vf = _t(qf), _t(np.zeros((B, 18)))
+        rpy, vs = _t(np.zeros((B, 3))), _t(np.zeros((B, 12)))
+        handed, orig_solve = [], ctl._b.mpc_solve
+
+        def spy(xs, fs, k, out=None):
+            handed.append((xs, fs, k))
+            return orig_solve(xs, fs, k, out=out)
+
+        ctl._b.mpc_solve = spy
+        clones = []
+        for k in range(50):
+            r = ctl.compute(vref, qf, vf, rpy, vs)
+            if k % 10 == 0:
+                clones.append((ctl._pre["xref"].clone(), ctl._pre["fsteps"].clone()))
+            qf[:, 7:].copy_(r.q_des)
+            vf[:, 6:].copy_(r.v_des)
+        torch.cuda.synchronize()
+        assert ctl._n_issued == 5 and len(handed) == 5
+        # the last three solves' snapshot buffers still hold exactly what the planners produced at their issue
+        for n in (2, 3, 4):
+            xs, fs, k = handed[n]
+            assert k == 10 * n and torch.equal(xs, clones[n][0]) and torch.equal(fs, clones[n][1]), n
+        st = ctl.stats()["mpc"]
+        assert (st["status"] == 1).all()
+        assert ctl._adopted is not None and int((ctl.error_flag != 0).sum().item()) == 0
+        assert bool(torch.isfinite(ctl._res["result"]).all())
+        ctl.stop_parallel_loop()

@@ -187,3 +187,83 @@ def test_contact_patterns_from_flight_to_full_stance(oracle_mod, synth_mod):
             for key, ref in (("tau_ff", r.tau_ff), ("qdes", r.qdes), ("vdes", r.vdes[:, 0]),
                              ("f_with_delta", r.f_with_delta[:, 0]), ("ddq_res", r.ddq_res)):
                 assert rel_err(o[key][b], ref) < RTOL, (s, b, key, contacts[b])
+
+
+def _full_size_pipeline(synth_mod, B, N, gaits, seed0, steps=3):
+    """MPC -> WBC for `steps` control steps at a BASELINE batch size; returns the last step's data and outputs."""
+    import qrw_hip
+
+    N_gait = max(20, N + 4)
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, seed0=seed0)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    for s in range(steps):
+        d = sb.step(s)
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        f_cmd = np.ascontiguousarray(out[:, 12:, 0])
+        w = eng.wbc_compute_host(d["q"], d["dq"], f_cmd, d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+    return sb, eng, d, out, f_cmd, w
+
+
+def _check_full_size_properties(eng, d, out, f_cmd, w, B, N):
+    ms, ws = eng.mpc_stats(), eng.wbc_stats()
+    assert (ws["status"] == 1).all() and (ws["iters"] % 25 == 0).all()
+    assert (ms["status"] == 1).mean() > 0.98 and np.isin(ms["status"], (1, 2, -2)).all()  # rare max-iter runs pass through like in the reference
+    for key in ("tau_ff", "qdes", "vdes", "f_with_delta", "ddq_res"):
+        assert np.isfinite(w[key]).all(), key
+    f = w["f_with_delta"].reshape(B, 4, 3)
+    mu = 0.9
+    tol = 1e-3  # eps_abs = eps_rel = 1e-5 on rows of size <= 25 (src/QPWBC.cpp:239-240)
+    assert (f[:, :, 2] >= -tol).all() and (f[:, :, 2] <= 25 + tol).all()
+    assert (np.abs(f[:, :, 0]) <= mu * f[:, :, 2] + tol).all() and (np.abs(f[:, :, 1]) <= mu * f[:, :, 2] + tol).all()
+    swing = d["contacts"] == 0
+    assert np.abs(f[swing]).max() < 5e-2  # Jc rows and f_cmd are zero there: only the 5 I regularisation acts
+    # tau_ff is bounded by what the security check would accept by a wide margin on nominal states (Controller.py:345-355)
+    assert np.abs(w["tau_ff"]).max() < 20.0
+    assert np.allclose(w["qdes"][:, :7], 0.0) and np.allclose(w["vdes"][:, :6], 0.0)  # scripts/solo12InvKin.py:62-67
+
+
+def test_config3_batch4096_mpc_wbc_properties(synth_mod):
+    """BASELINE config 3 at full size (batch 4096, N = 16, MPC + QPWBC + InvKin): size-independent properties on every
+    instance and bit-equality of a spread of instances with an independent small-batch run of the same pipeline."""
+    import qrw_hip
+
+    B, N = 4096, 16
+    sb, eng, d, out, f_cmd, w = _full_size_pipeline(synth_mod, B, N, ("trot",), 20260000)
+    _check_full_size_properties(eng, d, out, f_cmd, w, B, N)
+    idx = np.array([0, 15, 16, 1023, 2049, 4095])
+    small = qrw_hip.Batch(len(idx), N)
+    for s in range(3):
+        d2 = sb.step(s)
+        o2 = small.mpc_solve_host(d2["xref"][idx], d2["fsteps"][idx], s)
+        w2 = small.wbc_compute_host(d2["q"][idx], d2["dq"][idx], np.ascontiguousarray(o2[:, 12:, 0]), d2["contacts"][idx],
+                                    d2["pgoals"][idx], d2["vgoals"][idx], d2["agoals"][idx])
+    assert np.array_equal(o2, out[idx])
+    for key in ("tau_ff", "f_with_delta", "qdes", "vdes", "ddq_res"):
+        assert np.array_equal(w2[key], w[key][idx]), key
+
+
+def test_config4_batch4096_n32_mixed_gaits_properties(oracle_mod, synth_mod):
+    """BASELINE config 4 at full size (batch 4096, N = 32, walk / trot / bounding per instance): the same properties,
+    bit-equality with a small-batch run, and oracle parity (iterations, 1e-4) on three instances."""
+    import qrw_hip
+
+    B, N = 4096, 32
+    gaits = ("walk", "trot", "bounding")
+    sb, eng, d, out, f_cmd, w = _full_size_pipeline(synth_mod, B, N, gaits, 20264000, steps=2)
+    _check_full_size_properties(eng, d, out, f_cmd, w, B, N)
+    fm = out[:, 12:, :].transpose(0, 2, 1).reshape(B, N, 4, 3)
+    gait = d["gait"][:, :N]
+    ok = eng.mpc_stats()["status"] == 1
+    assert np.abs(fm[ok][gait[ok] == 0]).max() < 1e-3
+    idx = np.array([1, 2, 3, 777, 4095])
+    small = qrw_hip.Batch(len(idx), n_steps=N, N_gait=36, T_gait=0.02 * N)
+    refs = [oracle_mod.MPC(0.02, N, 0.02 * N, 36) for _ in range(3)]
+    for s in range(2):
+        d2 = sb.step(s)
+        o2 = small.mpc_solve_host(d2["xref"][idx], d2["fsteps"][idx], s)
+        st = small.mpc_stats()
+        for j in range(3):
+            assert refs[j].run(s, d2["xref"][idx[j]], d2["fsteps"][idx[j]]) == 0
+            assert st["iters"][j] == refs[j].iter and rel_err(o2[j], refs[j].get_latest_result()) < RTOL
+    assert np.array_equal(o2, out[idx])
+    assert len(set(sb.kind[idx].tolist())) >= 2  # the spread covers more than one gait
