@@ -244,6 +244,9 @@ def test_async_free_running_startup_keeps_snapshots_intact():
             assert k == 10 * n and torch.equal(xs, clones[n][0]) and torch.equal(fs, clones[n][1]), n
         st = ctl.stats()["mpc"]
         assert (st["status"] == 1).all()
-        assert ctl._adopted is not None and int((ctl.error_flag != 0).sum().item()) == 0
+        r = ctl.compute(vref, qf, vf, rpy, vs)  # k = 50: issues solve 5; solves 0..4 have finished, its poll adopts solve 4
+        torch.cuda.synchronize()
+        assert ctl._adopted == 4 % 3 and [n for n, _ in ctl._pending] == [5]
+        assert int((ctl.error_flag != 0).sum().item()) == 0
         assert bool(torch.isfinite(ctl._res["result"]).all())
         ctl.stop_parallel_loop()
