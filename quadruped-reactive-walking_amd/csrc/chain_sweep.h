@@ -106,13 +106,19 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
     for (int c = 0; c < 12; c++) b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     b.r = pr[(2 * p + 1) * 12];
   };
+#ifdef QRW_EXPERIMENT_NODEP  // TIMING EXPERIMENT ONLY (wrong results): every step multiplies the sweep's first vector, so
+  const double x_first = x;   // that no step depends on the one before it -- the most any re-association of the sweeps
+#define QRW_XIN x_first       // into shorter dependent chains could gain (scripts/gpu_iter_time.sh)
+#else
+#define QRW_XIN x
+#endif
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
+    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t1, computed in lanes 0..31
     x = swap_halves(x);           // now in lanes 32..63
     if (t1 == LB) pB = x;
     (t1 < LB ? ps_odd : ps_oddA)[t1 * 12] = x;
-    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
+    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t2, computed in lanes 32..63
     if (t2 < LA) {
       x = swap_halves(x);         // now in lanes 0..31
       ps_even[t2 * 12] = x;
@@ -151,6 +157,9 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   double* ps_even = (own && h == 0) ? px : dump;          // even steps t < LA (stored after the exchange), both chains
   double* ps_lastA = (own && h == 1 && !rw) ? px : dump;  // step LA (even, not exchanged): chain A only
   double x = sX[m * 12 + i];
+#ifdef QRW_EXPERIMENT_NODEP
+  const double x_first = x;
+#endif
   ChainOp b0, b1;
   auto fetch = [&](ChainOp& b, int p) {
     const qrw_d2* q = reinterpret_cast<const qrw_d2*>(pm + (LA - 2 * p - 1) * kSlot);
@@ -164,10 +173,10 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   };
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
+    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t1, computed in lanes 0..31
     x = swap_halves(x);
     ps_odd[(LA - t1) * 12] = x;
-    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
+    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t2, computed in lanes 32..63
     if (t2 < LA) {
       x = swap_halves(x);
       ps_even[(LA - t2) * 12] = x;  // t2 < LA = LB + 1: both chains

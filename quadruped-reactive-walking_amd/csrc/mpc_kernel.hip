@@ -1052,7 +1052,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           done = true;
         }
       }
+#ifndef QRW_EXPERIMENT_NOTERM  // timing experiments: every instance runs max_iter iterations (launch time / iterations is exact)
       if (done) break;
+#endif
       if (iter % 200 == 0) {  // adapt_rho on the SCALED residuals (compute_rho_estimate)
         pres_s = block_max<NW>(pres_s, L.sRed, wv, lane); nz_s = block_max<NW>(nz_s, L.sRed, wv, lane);
         nax_s = block_max<NW>(nax_s, L.sRed, wv, lane); dres_s = block_max<NW>(dres_s, L.sRed, wv, lane);
