@@ -244,7 +244,11 @@ int qrw_device_cu_count(int32_t device, int32_t *n_cus);
 
 /* Diagnostic: checks on the device what the MPC solver's linear algebra relies on — the row_newbcast form of
  * v_fmac_f64, the twisted block sweeps in the production LDS layout and the in-register Gauss-Jordan inverse
- * (csrc/chain_sweep.h) — against a host evaluation. 0 = ok, 1 = mismatch, <0 = HIP error. *max_err may be NULL. */
+ * (csrc/chain_sweep.h) — against a host evaluation — and then one whole known-answer MPC solve (the reference's
+ * four-stance immobile scenario, scripts/test_mpc.py:54-62: 350 ADMM iterations, equal vertical forces, see
+ * csrc/qrw_api.hip).  0 = ok, 1 = sweep mismatch, 2 = the known-answer solve is wrong, <0 = HIP error. *max_err (of the
+ * sweep check) may be NULL.  qrw_create runs the known-answer solve once per process and device and fails with -20 if
+ * this build of the library computes wrong results. */
 int qrw_selftest_sweeps(double *max_err);
 
 /* workspace sizes, for callers that budget HBM */

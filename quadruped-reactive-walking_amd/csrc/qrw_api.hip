@@ -110,6 +110,70 @@ static void base_inertia_diag(double Y[6]) {
   Y[5] = I[2];
 }
 
+
+// Known-answer check of THIS build of mpc_solve_kernel, run once per process and device by qrw_create (and by
+// qrw_selftest_sweeps).  Why it exists: the kernel lives at the edge of the register file, and one combination of compiler
+// options has produced a library in which every solve diverges; the parity tests catch that, a deployment
+// that only rebuilds the library would not.  Case: the reference's four-stance immobile scenario (scripts/test_mpc.py:
+// 54-62: height 0.2447..., feet at (+-0.195, +-0.147)), first MPC call, N = 16.  Expected values recorded from the CPU
+// restatement (oracle/, 2026-10): 350 ADMM iterations (one rho adaptation at iteration 200), rho 1.03905792582975e-3,
+// four equal vertical forces summing to 24.5347812847 N (m g = 24.525 N), horizontal forces zero.
+static int mpc_known_answer_check(double* worst) {
+  constexpr int N = 16, Ng = 20, T = 64;
+  double hx[12 * (N + 1)] = {0}, hf[Ng * 12] = {0}, hout[24 * N];
+  for (int c = 0; c <= N; c++) hx[2 * (N + 1) + c] = 0.24474949993103629;
+  const double feet[12] = {0.195, 0.147, 0., 0.195, -0.147, 0., -0.195, 0.147, 0., -0.195, -0.147, 0.};
+  for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) hf[k * 12 + i] = feet[i];
+  struct Buf { void* p = nullptr; ~Buf() { if (p) hipFree(p); } };
+  Buf bx, bf, bo, bst, bg, bi, bd;
+  const size_t n_int = 8, n_dbl = 16;
+  if (hipMalloc(&bx.p, sizeof(hx)) != hipSuccess || hipMalloc(&bf.p, sizeof(hf)) != hipSuccess || hipMalloc(&bo.p, sizeof(hout)) != hipSuccess ||
+      hipMalloc(&bst.p, qrw::kMpcStItems * T * sizeof(double)) != hipSuccess || hipMalloc(&bg.p, Ng * 4 * sizeof(int)) != hipSuccess ||
+      hipMalloc(&bi.p, n_int * sizeof(int)) != hipSuccess || hipMalloc(&bd.p, n_dbl * sizeof(double)) != hipSuccess)
+    return -10;
+  hipMemcpy(bx.p, hx, sizeof(hx), hipMemcpyHostToDevice);
+  hipMemcpy(bf.p, hf, sizeof(hf), hipMemcpyHostToDevice);
+  hipMemset(bst.p, 0, qrw::kMpcStItems * T * sizeof(double));
+  hipMemset(bg.p, 0, Ng * 4 * sizeof(int));
+  hipMemset(bi.p, 0, n_int * sizeof(int));
+  hipMemset(bd.p, 0, n_dbl * sizeof(double));
+  qrw::MpcArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = 1; a.N = N; a.N_gait = Ng; a.dt = 0.02;
+  a.xref = (const double*)bx.p; a.fsteps = (const double*)bf.p; a.num_iter = nullptr; a.num_iter_scalar = 0;
+  a.out = (double*)bo.p; a.st = (double*)bst.p; a.gait = (int*)bg.p;
+  int* ip = (int*)bi.p; double* dp = (double*)bd.p;
+  a.flags = ip; a.iters = ip + 1; a.status = ip + 2; a.rho_updates = ip + 3;
+  a.rho_out = dp; a.pri = dp + 1; a.dua = dp + 2; a.prof = nullptr; a.order = nullptr;
+  if (qrw::mpc_launch(a, nullptr) != 0) return -11;
+  if (hipDeviceSynchronize() != hipSuccess) return -12;
+  int hi[n_int]; double hd[n_dbl];
+  hipMemcpy(hi, bi.p, sizeof(hi), hipMemcpyDeviceToHost);
+  hipMemcpy(hd, bd.p, sizeof(hd), hipMemcpyDeviceToHost);
+  hipMemcpy(hout, bo.p, sizeof(hout), hipMemcpyDeviceToHost);
+  double err = 0.0, fz = 0.0;
+  for (int j = 0; j < 4; j++) {
+    fz += hout[(12 + 3 * j + 2) * N];
+    err = fmax(err, fabs(hout[(12 + 3 * j + 2) * N] - hout[14 * N]));      // equal vertical forces
+    err = fmax(err, fabs(hout[(12 + 3 * j) * N]) + fabs(hout[(12 + 3 * j + 1) * N]));  // no horizontal force
+  }
+  err = fmax(err, fabs(fz - 24.534781284726584));
+  err = fmax(err, fabs(hd[0] / 1.0390579258297492e-3 - 1.0));
+  if (!(err == err)) err = 1e300;  // NaN
+  if (worst) *worst = err;
+  return (hi[1] == 350 && hi[2] == qrw::kStatusSolved && err < 1e-8) ? 0 : 1;
+}
+static int g_kat_state[64] = {0};  // per device: 0 not run, 1 passed, -1 failed
+static int mpc_known_answer_once(int device) {
+  if (device < 0 || device >= 64) return 0;
+  if (g_kat_state[device] == 0) {
+    double w = 0.0;
+    const int rc = mpc_known_answer_check(&w);
+    g_kat_state[device] = (rc == 0) ? 1 : -1;
+  }
+  return g_kat_state[device] == 1 ? 0 : 1;
+}
+
 extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   if (!cfg || !out) return fail(-1, "qrw_create: null argument");
   if (cfg->batch < 1) return fail(-1, "qrw_create: batch must be >= 1");
@@ -121,6 +185,10 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
     return fail(-2, "qrw_create: no HIP device (this library has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(-2, "qrw_create: bad device ordinal");
   DeviceScope dev_scope__(cfg->device);
+  if (mpc_known_answer_once(cfg->device) != 0)
+    return fail(-20, "qrw_create: the known-answer self-test of mpc_solve_kernel failed on this device: this build of libqrw_hip.so "
+                     "computes wrong results (a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild "
+                     "with the Makefile's flags");
   qrw_handle h = new qrw_handle_s();
   h->cfg = *cfg;
   const size_t B = (size_t)cfg->batch;
@@ -483,7 +551,12 @@ extern "C" int qrw_get_base_inertia_diag(qrw_handle h, double* h_Y6) {
 extern "C" int qrw_selftest_sweeps(double* max_err) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_sweeps: no HIP device");
-  return qrw::sweeps_selftest(max_err);
+  const int rc = qrw::sweeps_selftest(max_err);
+  if (rc != 0) return rc;
+  double kat_err = 0.0;
+  const int krc = mpc_known_answer_check(&kat_err);  // the whole solve, not only its sweeps
+  if (krc != 0) return fail(2, "qrw_selftest_sweeps: known-answer MPC solve failed");
+  return 0;
 }
 
 // Diagnostic (profiling builds only, -DQRW_PROFILE_PHASES): per-instance shader-clock totals of the MPC kernel phases.

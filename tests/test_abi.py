@@ -60,3 +60,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "qrw_oracle" not in src and "osqp_restate" not in src, f
+
+
+def test_shipped_mpc_kernel_spills_nothing_to_scratch():
+    """The MPC kernel lives at the edge of the register file (256 VGPRs + ~254 AGPRs).  The one build on record that
+    computed wrong results was one in which the allocator ran out of accumulation registers and went to
+    scratch; the shipped flags must leave the N = 16 instantiation with no scratch and with AGPRs to spare."""
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    mpcflags = re.search(r"^MPCFLAGS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-pass-failed",
+                        "-Rpass-analysis=kernel-resource-usage"] + mpcflags +
+                       [os.path.join(csrc, "mpc_kernel.hip"), "-o", os.devnull], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blk = r.stderr.split("mpc_solve_kernelILi1ELb1E")[1]
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+    agprs = int(re.search(r"AGPRs: (\d+)", blk).group(1))
+    vspill = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
+    assert scratch == 0 and vspill == 0 and agprs < 256, (scratch, vspill, agprs)
