@@ -1,21 +1,31 @@
 #!/bin/bash
 # On the GPU box (through gpurun, from the repo root): everything profiles/ is refreshed from, into gpurun_out/refresh/.
+# ROUND tags the file names (profiles/ keeps one set per round).
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r2}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-python3 bench.py > $OUT/r1_bench_line.json 2> $OUT/bench.err
+python3 bench.py > $OUT/${ROUND}_bench_line.json 2> $OUT/bench.err
 echo "bench done"
-python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline > $OUT/r1_bench_line_n32_mixed.json 2> $OUT/bench32.err
+python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_mixed.json 2> $OUT/bench32.err
 echo "bench n32 done"
-python3 bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/bench_b1.json 2>> $OUT/bench.err
-python3 bench.py --batch 256 --no-cpu-baseline --no-secondary > $OUT/bench_b256.json 2>> $OUT/bench.err
-python3 bench.py --batch 16384 --no-cpu-baseline --no-secondary > $OUT/bench_b16384.json 2>> $OUT/bench.err
+python3 bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_b1.json 2>> $OUT/bench.err
+python3 bench.py --batch 256 --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_b256.json 2>> $OUT/bench.err
+python3 bench.py --batch 16384 --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_b16384.json 2>> $OUT/bench.err
 echo "batch sweep done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/r1_bench_line_under_rocprof.json 2> $OUT/stats.err
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r1_kernel_stats_bench_b4096.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_under_rocprof.json 2> $OUT/stats.err
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_b4096.csv
+cp $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_b4096.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32 -o st -- python3 $R/bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_under_rocprof.json 2> $OUT/stats32.err
+cp $(find $OUT/stats32 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_n32_mixed.csv
+cp $(find $OUT/stats32 -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_n32.csv
 echo "rocprof stats done"
-cd $R && bash scripts/pmc_profile.sh > $OUT/pmc.log 2>&1 && cp $R/gpurun_out/pmc_r1/summary.json $OUT/r1_pmc_summary_bench_b4096.json
+cd $R && ROUND=$ROUND bash scripts/pmc_profile.sh > $OUT/pmc.log 2>&1 && cp $R/gpurun_out/pmc_$ROUND/summary.json $OUT/${ROUND}_pmc_summary_bench_b4096.json
 echo "pmc done"
+python3 scripts/trace_timed_avg.py $OUT/kernel_trace_b4096.csv 20 > $OUT/${ROUND}_timed_launch_avg_b4096.txt
+python3 scripts/trace_timed_avg.py $OUT/kernel_trace_n32.csv 20 > $OUT/${ROUND}_timed_launch_avg_n32.txt
+for n in 16 32; do QRW_PHASES_N=$n python3 scripts/gpu_phases.py > $OUT/${ROUND}_mpc_phase_cycles_n$n.txt 2>/dev/null; done
+echo "phases done"
