@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -262,7 +263,8 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   a.order = h->mpc_have_order ? h->mpc_order : nullptr;
   if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
-  if (h->cfg.batch > 1024) {
+  static const int order_min = getenv("QRW_ORDER_MIN") ? atoi(getenv("QRW_ORDER_MIN")) : 1024;  // experiments only
+  if (h->cfg.batch > order_min) {
     if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_ema, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: order kernel launch failed", hipGetLastError());
     h->mpc_have_order = true;
