@@ -355,6 +355,12 @@ class MPCBatch:
             self._lib.mpc_oracle_destroy(h)
         self._hs = []
 
+    def iters(self):
+        """ADMM iteration counts / statuses of the last run, per instance (tests only)."""
+        it = np.array([self._lib.mpc_oracle_iter(h) for h in self._hs], dtype=np.int32)
+        st = np.array([self._lib.mpc_oracle_status(h) for h in self._hs], dtype=np.int32)
+        return it, st
+
     def run(self, num_iter, xref, fsteps, threads):
         ni = np.ascontiguousarray(np.broadcast_to(np.asarray(num_iter, np.int32), (self.B,)))
         xref = _arr(xref, (self.B, 12, self.n_steps + 1))

@@ -321,3 +321,36 @@ def test_config2_batch256_mpc_only(oracle_mod, synth_mod):
     f = out[:, 12:, :].transpose(0, 2, 1).reshape(B, N, 4, 3)
     gait = d["gait"][:, :N]
     assert np.abs(f[gait == 0]).max() < 1e-3 and (f[gait == 1][:, 2] > -1e-3).all()
+
+
+@pytest.mark.parametrize("N,gaits,B", [(16, ("trot",), 1024), (16, ("walk", "trot", "bounding", "pacing"), 512),
+                                       (32, ("walk", "trot", "bounding"), 256)])
+def test_wide_oracle_parity_sample(oracle_mod, synth_mod, N, gaits, B):
+    """Oracle parity on a wide sample in the driver-run suite (the oracle stepped with one instance per host thread):
+    EVERY instance of every call must take the oracle's iteration count and status and match it to 1e-4 (measured
+    ~1e-10).  Open-loop noisy states, 6 calls: warm start, adaptive rho and (N = 32) max-iter exits are all exercised."""
+    import qrw_hip
+
+    N_gait = max(20, N + 4)
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, seed0=20270000 + N)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    ref = oracle_mod.MPCBatch(B, 0.02, N, 0.02 * N, N_gait, fast=False)  # the strict checker build
+    threads = max(1, min(16, len(__import__("os").sched_getaffinity(0))))
+    worst = 0.0
+    seen_status = set()
+    for s in range(6):
+        d = sb.step(s)
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        r = ref.run(s, d["xref"], d["fsteps"], threads)
+        it, st = ref.iters()
+        g = eng.mpc_stats()
+        assert np.array_equal(g["iters"], it), (s, np.nonzero(g["iters"] != it)[0][:8])
+        assert np.array_equal(g["status"], st), s
+        seen_status |= set(st.tolist())
+        scale_x = np.abs(r[:, :12]).max(axis=(1, 2), keepdims=True)
+        scale_f = np.maximum(np.abs(r[:, 12:]).max(axis=(1, 2), keepdims=True), 1e-12)
+        e = max((np.abs(out[:, :12] - r[:, :12]) / scale_x).max(), (np.abs(out[:, 12:] - r[:, 12:]) / scale_f).max())
+        worst = max(worst, e)
+        assert e < RTOL, (s, e)
+    assert 1 in seen_status
+    print("wide parity N=%d B=%d: worst relative deviation %.2e, statuses %s" % (N, B, worst, sorted(seen_status)))
