@@ -150,8 +150,14 @@ def main():
         dev = torch.device("cuda", local_rank)
     dist = None
     backend = None
-    if world > 1:
+    # QRW_FORCE_COLLECTIVE=1: run the N > 1 code path (process group, per-step all-gather pipeline, both timed regions)
+    # with however many ranks there are -- one RCCL rank on a 1-GPU box exercises the real nccl calls of that path
+    multi = world > 1 or os.environ.get("QRW_FORCE_COLLECTIVE") == "1"
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("QRW_DIST_BACKEND", "gloo" if stub else "nccl")
         if backend == "nccl":
@@ -166,7 +172,7 @@ def main():
     N_gait = max(20, N + 4)
     W, K = max(args.warmup, 1), args.steps  # the first call (num_iter == 0) is the QP setup: always untimed
     gaits = tuple(args.gaits.split(","))
-    collective = world > 1 and not args.no_collective
+    collective = multi and not args.no_collective
     n_regions = 2 if collective else 1      # N > 1: a second timed region without the all-gather, same line
     n_in = W + n_regions * K
     sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=n_in, b0=rank * B)
@@ -189,7 +195,7 @@ def main():
     mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
     f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
     wbc_bufs = [None, None]  # two output sets: the gather of step s reads one while step s+1 writes the other
-    pipe = TorqueGatherPipeline(B, dev) if world > 1 else None
+    pipe = TorqueGatherPipeline(B, dev) if multi else None
     mk_ev = (lambda: torch.cuda.Event(enable_timing=True)) if not stub else (lambda: None)
     ev = [(mk_ev(), mk_ev()) for _ in range(n_regions * K)]
     ev_w = [(mk_ev(), mk_ev()) for _ in range(n_regions * K)]
@@ -216,7 +222,7 @@ def main():
             pipe.issue(i, wbc_bufs[i]["tau_ff"])   # all-gather on the side stream, overlaps the next step
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         if not stub:
             torch.cuda.synchronize()
@@ -230,14 +236,14 @@ def main():
             pipe.drain()  # the last all-gather belongs to the timed work
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el
 
     ranks_seen = [0]
-    if world > 1:
+    if multi:
         me = torch.tensor([rank], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         seen = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(seen, me)
@@ -264,7 +270,7 @@ def main():
                                "SURVEY 8(d), which is reported beside it as closed_loop_sequence)" % ("/".join(gaits), B, N),
                    "batch_per_gpu": B, "n_steps": N, "gaits": list(gaits), "parallelism": "batch-sharded x%d" % world},
     }
-    if world > 1:
+    if multi:
         out["collective"] = {
             "op": "all_gather of joint torques, one per control step, side stream, overlapped with the next step"
                   if collective else "none (--no-collective)",
@@ -314,7 +320,7 @@ def main():
             out["torque_max_abs_err"] = out["accuracy"]["torque_max_abs_err"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -122,3 +122,17 @@ def test_bench_two_ranks_on_one_gpu_real_kernels():
     assert line["n_gpus"] == 2 and line["data"] == "synthetic"
     assert line["collective"]["ranks_seen"] == [0, 1] and line["collective"]["gathered_block_check"] is True
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["launches"] == 3
+
+
+@pytest.mark.gpu
+def test_bench_collective_path_on_one_rccl_rank():
+    """The N > 1 branch of bench.py with the REAL RCCL calls (process group `nccl`, all_gather_into_tensor on the side
+    stream behind an event, stream-level wait before a torque buffer is reused, checksummed last block), on the one rank a
+    1-GPU box can host (QRW_FORCE_COLLECTIVE=1).  What more ranks add is only what RCCL itself does."""
+    r, line = _run_bench({"QRW_FORCE_COLLECTIVE": "1"}, "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "256",
+                         "--no-cpu-baseline", "--no-secondary")
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = line["collective"]
+    assert "RCCL" in c["backend"] and c["ranks_seen"] == [0] and c["gathered_block_check"] is True
+    assert c["bytes_per_rank_per_step"] == 256 * 12 * 8 and c["no_collective_steps_per_s"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0
