@@ -310,6 +310,8 @@ def main():
         if not args.no_secondary:
             out["two_stream_groups"] = stream_groups_figure(B, N, N_gait, dev, W, K, dict(
                 xref=xref, fsteps=fsteps, q=q, dq=dq, contacts=contacts, pgoals=pg, vgoals=vg, agoals=ag))
+            out["pipelined_sequence"] = pipelined_sequence_figure(B, N, N_gait, dev, W, K, dict(
+                xref=xref, fsteps=fsteps, q=q, dq=dq, contacts=contacts, pgoals=pg, vgoals=vg, agoals=ag))
             out["closed_loop_sequence"] = closed_loop_sequence(B, N, N_gait, gaits, dev, W, K)
             out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
@@ -390,6 +392,48 @@ def stream_groups_figure(B, N, N_gait, dev, W, K, data, S=2):
             "what": "the headline workload with the batch split into %d independent stream groups (own handle + stream each, "
                     "no cross-group synchronisation inside the timed region): straggling solves of one group overlap the "
                     "next step of the other" % S}
+
+
+def pipelined_sequence_figure(B, N, N_gait, dev, W, K, data):
+    """The headline's K timed steps (same inputs, bit-identical results) submitted as ONE qrw_mpc_solve_sequence launch —
+    persistent workgroups, a task queue that orders each instance's consecutive solves and nothing else — followed by the
+    K WBC steps.  Legitimate only where all K steps' inputs exist beforehand (log replay, open-loop sweeps: the headline's
+    open-loop sequence is such a case, a closed control loop is not), hence a secondary figure: it shows what the
+    device-wide barrier between the steps of independent robots costs (the launch tail of DESIGN.md 4.1)."""
+    import torch
+
+    import qrw_hip
+
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
+    w = None
+    for s in range(W):  # warm-up exactly as the headline: ordinary calls (the first one sets the QPs up)
+        o = eng.mpc_solve(data["xref"][s], data["fsteps"][s], s)
+        f_cmd.copy_(o[:, 12:, 0])
+        w = eng.wbc_compute(data["q"][s], data["dq"][s], f_cmd, data["contacts"][s], data["pgoals"][s], data["vgoals"][s],
+                            data["agoals"][s], out=w)
+    xs = torch.stack(data["xref"][W:W + K])
+    fs = torch.stack(data["fsteps"][W:W + K])
+    outs = torch.empty((K, B, 24, N), dtype=torch.float64, device=dev)
+    its = torch.zeros((K, B), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.mpc_solve_sequence(xs, fs, W, out=outs, iters=its)
+    for i in range(K):
+        s = W + i
+        f_cmd.copy_(outs[i][:, 12:, 0])
+        w = eng.wbc_compute(data["q"][s], data["dq"][s], f_cmd, data["contacts"][s], data["pgoals"][s], data["vgoals"][s],
+                            data["agoals"][s], out=w)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    bad = eng.mpc_sequence_timed_out()
+    it = its.cpu().numpy().astype(np.float64)
+    eng.close()
+    flops = it.sum() * f_iter(N) + K * B * (f_fac(N) + F_ASM)
+    return {"value": B * K / el, "unit": "steps/s", "ms_per_step": 1e3 * el / K, "mean_admm_iters": float(it.mean()),
+            "fp64_frac_over_region": float(flops / el / PEAK_FP64), "queue_timed_out": bool(bad),
+            "what": "the headline's %d timed steps as one qrw_mpc_solve_sequence launch (per-instance ordering only) + %d WBC "
+                    "steps; inputs of all steps resident beforehand" % (K, K)}
 
 
 def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):

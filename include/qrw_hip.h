@@ -76,6 +76,19 @@ int qrw_mpc_solve_host(qrw_handle h, const double *h_xref, const double *h_fstep
  * h_gait [N_gait][4], h_Sgait [12 N] */
 int qrw_mpc_get_gait(qrw_handle h, int32_t b, double *h_gait, double *h_Sgait);
 
+/* K consecutive MPC::run calls of every instance (call indices first_num_iter .. first_num_iter + K - 1) in ONE launch:
+ * d_xref [K][B][12][N+1], d_fsteps [K][B][N_gait][12] -> d_out [K][B][24][N], d_iters [K][B] int32 (may be NULL).  Results
+ * and the persistent solver state afterwards are those of K calls of qrw_mpc_solve, bit for bit; what differs is the
+ * ordering: there is no device-wide barrier between the calls, only each instance's own order (a task queue hands call s+1
+ * of an instance out when its call s has finished), so one instance's long solve delays nobody else's next call.  For
+ * inputs that are all known beforehand — replaying the planner outputs a log holds (`planner_xref`, `planner_fsteps`,
+ * scripts/LoggerControl.py:61-65,142-143) to recompute `mpc_x_f` (:76,:152), or open-loop evaluation sweeps — not for a
+ * closed control loop, whose next inputs depend on this call's result.  qrw_mpc_sequence_error reports (after the stream
+ * has been synchronised) whether the queue ever timed out (2 s without the awaited predecessor finishing; never expected). */
+int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double *d_xref, const double *d_fsteps, int32_t first_num_iter,
+                           double *d_out, int32_t *d_iters, void *stream);
+int qrw_mpc_sequence_error(qrw_handle h, int32_t *timed_out);
+
 /* Device-to-device copy of the last solve's ADMM iteration counts (int32 [B]) on `stream`: lets a caller keep per-launch
  * work statistics in HBM without a host round trip inside a timed region (bench.py's roofline accounting).  No reference
  * counterpart: OSQP's info->iter is never read by the reference (src/MPC.cpp:558). */

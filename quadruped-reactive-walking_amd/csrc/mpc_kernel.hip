@@ -364,16 +364,145 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
   }
 }
 
+// ---- task queues of the sequence kernel (qrw_mpc_solve_sequence).  A task = call * B + instance; K * B tasks in all.
+// Why more than one queue: with a single FIFO a ready task waits behind ~3 B / 4 others (3.8 ms at batch 4096 on 1024
+// resident workgroups), and an instance that needs ~2000 iterations call after call (there are such: 38 650 iterations in
+// 20 calls against a mean of 10 300) pays that wait on top of every one of its long solves: its chain, not the work, ends
+// the sequence (measured: 6.7 ms per call, slower than one launch per call).  The instances are therefore ranked by the
+// longest-first order of the handle (moving average of their iteration counts) into kSeqLevels levels (the first 1/16, up to 1/4, up to 1/2 of the order, the rest), each with its own
+// FIFO, and a workgroup looking for work takes from the highest level that has a task: the long chains never wait, the
+// short tasks absorb the waiting.
+//   Per level l: tasks in queue[base_l + slot], -1 while unfilled; head (next slot to take) and tail (next slot to fill) in
+//   words kSeqStride * l and + 1 of qctr (one 64-byte line per level).  Slots are RESERVED with fetch_add (no
+//   compare-and-swap loops, no shared line polled by everybody): a workgroup reserves in a level only when it sees
+//   head < tail there — or, in the lowest level, whenever that level still has tasks to come — and then waits for its own
+//   slot.  Seeing head < tail and losing the race leaves it with a slot that the level's next finished task fills.
+//   A level of n instances sees exactly n * K tasks: a reserved slot beyond that means the level is exhausted.
+//   The first tasks (as many as there are workgroups) are dealt by workgroup index, not through the queues: a thousand
+//   workgroups starting together would otherwise all reserve in level 0.
+// Hand-off of an instance's solver state between workgroups on different CUs / XCDs: release at agent scope by the
+// finishing workgroup after its stores have left (s_waitcnt vmcnt(0)), relaxed queue store; relaxed polls, then ONE acquire
+// at agent scope by the taking workgroup (MI355X guide, inter-workgroup visibility: L1 is never refreshed by other CUs'
+// stores, the XCDs' L2s are not coherent with each other).  Measured: dropping the fences changes results (stale state).
+constexpr int kSeqLevels = 4;
+constexpr int kSeqStride = 16;                     // unsigned words per level in qctr
+static_assert(kSeqLevels * kSeqStride + 16 + kSeqLevels <= kSeqQctrWords, "qctr too small");
+constexpr int kSeqErr = kSeqLevels * kSeqStride;
+static_assert(kSeqErr == kSeqErrWord, "qrw_kernels.h and mpc_kernel.hip disagree on the queue counters' layout");   // error flag; + 1 diagnostics; + 2 + l: tasks through level l's queue; + 16 + l: its base
+__device__ __forceinline__ unsigned q_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int NW>
+__device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long long* sh, int tid, bool first_pass) {
+  int task = -1;
+  if (tid == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    if (first_pass) {  // dealt by workgroup index (the init kernel left these out of the queues)
+      task = ((int)blockIdx.x < a.B) ? a.seq_first[blockIdx.x] : -1;
+    }
+    bool give_up = first_pass;
+    while (task < 0 && !give_up) {
+      bool all_done = true;
+      for (int l = 0; l < kSeqLevels && task < 0; l++) {
+        const unsigned n_tot = a.qctr[kSeqErr + 2 + l];  // tasks that pass through this level's queue (init kernel)
+        if (n_tot == 0) continue;
+        unsigned* head = &a.qctr[l * kSeqStride];
+        const unsigned h = q_load(head);
+        if (h >= n_tot) continue;  // exhausted
+        all_done = false;
+        if (h < q_load(head + 1) || l == kSeqLevels - 1) {
+          const unsigned slot = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (slot >= n_tot) continue;
+          const int* q = a.queue + a.qctr[kSeqErr + 16 + l] + slot;
+          for (;;) {
+            task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (task >= 0) break;
+            __builtin_amdgcn_s_sleep(32);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: the task never came; give up, loudly
+              __hip_atomic_store(&a.qctr[kSeqErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              give_up = true;
+              break;
+            }
+          }
+        }
+      }
+      if (task >= 0 || all_done) break;
+      __builtin_amdgcn_s_sleep(127);  // upper levels empty right now and the lowest one exhausted: look again in a few microseconds
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        __hip_atomic_store(&a.qctr[kSeqErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        give_up = true;
+      }
+    }
+    if (task >= 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef QRW_SEQ_STATS  // diagnostics: 100 MHz ticks spent looking for work, summed over the workgroups
+    __hip_atomic_fetch_add(&a.qctr[kSeqErr + 1], (unsigned)(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  }
+  if constexpr (NW == 1) {
+    task = __builtin_amdgcn_readfirstlane(task);
+  } else {
+    int* si = reinterpret_cast<int*>(sh);
+    __syncthreads();  // the previous task's last LDS reads are done
+    if (tid == 0) si[0] = task;
+    __syncthreads();
+    task = si[0];
+    __syncthreads();
+  }
+  return task;
+}
+template <int NW>
+__device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq_s, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of the instance's state and results have left
+  if constexpr (NW > 1) __syncthreads();
+  if (tid == 0 && seq_s + 1 < a.seq_K) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int l = a.seq_hot[b];
+    const unsigned slot = __hip_atomic_fetch_add(&a.qctr[l * kSeqStride + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.queue[a.qctr[kSeqErr + 16 + l] + slot], (seq_s + 1) * a.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // FULL: N == 16 * NW, every lane owns a live horizon step (the masks on `act` fold away)
-template <int NW, bool FULL>
-__global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
+// SEQ = false: one workgroup solves one instance's one MPC call (qrw_mpc_solve).
+// SEQ = true:  persistent workgroups work through K consecutive calls of every instance (qrw_mpc_solve_sequence): tasks
+//   (call s, instance b) come from a queue in global memory; a task is queued when its predecessor (s-1, b) has finished,
+//   so the only ordering is per instance and one instance's long solve delays nobody else's next call.
+//   The sequence form reads its argument block from memory at the start of every task and derives the per-lane constants
+//   anew (both behind an opaque asm), so that nothing but a pointer and the thread id is live across tasks: hoisted out
+//   of the task loop they cost 140 spilled SGPRs and 364 B of scratch per lane.
+template <int NW, bool FULL, bool SEQ>
+__global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a_in, const MpcArgs* a_mem) {
   __shared__ MpcLdsT<NW> L;
   constexpr int T = 64 * NW;  // threads per instance
   // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
   // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
   PH_DECL
-  const int b = a.order ? a.order[blockIdx.x] : blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  bool seq_first_pass = true;
+  for (;;) {  // SEQ: one task per pass; otherwise a single pass
+  int tid = threadIdx.x;
+  MpcArgs a_task;
+  if constexpr (SEQ) {
+    const MpcArgs* q = a_mem;
+    asm volatile("" : "+s"(q), "+v"(tid));
+    a_task = *q;
+  }
+  const MpcArgs& a = SEQ ? a_task : a_in;
+  const int lane = tid & 63, wv = tid >> 6;
+#ifdef QRW_SEQ_STATS
+  const unsigned long long task_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int b, seq_s = 0;
+  if constexpr (SEQ) {
+    const int task = seq_next_task<NW>(a, &L.sBal[0], tid, seq_first_pass);
+    seq_first_pass = false;
+    if (task < 0) return;  // every task has been handed out (or the queue timed out: a.qctr[2] is set)
+    seq_s = task / a.B;
+    b = task - seq_s * a.B;
+  } else {
+    b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+  }
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
   const bool act = FULL ? true : (k < N);
@@ -403,10 +532,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
   for (int t = 0; t < 3; t++) wX[t] = (j == 0) ? w_all[t] : (j == 1) ? w_all[3 + t] : (j == 2) ? w_all[6 + t] : w_all[9 + t];
 
-  const double* xr = a.xref + (size_t)b * 12 * (N + 1);
-  const double* fs = a.fsteps + (size_t)b * a.N_gait * 12;
+  const size_t io = (size_t)seq_s * a.B + b;  // call-major input / output blocks ([K][B][...]; K = 1 outside sequences)
+  const double* xr = a.xref + io * 12 * (N + 1);
+  const double* fs = a.fsteps + io * a.N_gait * 12;
+  double* outp = a.out + io * 24 * N;
   double* st = a.st + (size_t)b * kMpcStItems * T;
-  const int num_iter = a.num_iter ? a.num_iter[b] : a.num_iter_scalar;
+  const int num_iter = (a.num_iter ? a.num_iter[b] : a.num_iter_scalar) + seq_s;
   const bool first = (num_iter == 0);
 #define ST(item) st[(item)*T + tid]
 
@@ -418,13 +549,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     if (act) {
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        a.out[(size_t)b * 24 * N + (3 * j + t) * N + k] = nan("");
-        a.out[(size_t)b * 24 * N + (12 + 3 * j + t) * N + k] = nan("");
+        outp[(3 * j + t) * N + k] = nan("");
+        outp[(12 + 3 * j + t) * N + k] = nan("");
       }
     }
-    return;
-  }
-
+    if (SEQ && tid == 0 && a.seq_iters) a.seq_iters[io] = 0;
+  } else {
   // =========================== A. assemble (MPC.cpp:626-640) ===========================
   // construct_gait (:686-701): rows until the first all-zero row of fsteps
   double f3[3] = {0, 0, 0};
@@ -1095,8 +1225,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       const int i = 3 * j + t;
       const double sx = has_sol ? xhX[t] + xr[i * (N + 1) + k + 1] : nan("");
       const double sf = has_sol ? xhF[t] : nan("");
-      a.out[(size_t)b * 24 * N + i * N + k] = sx;           // retrieve_result, MPC.cpp:573
-      a.out[(size_t)b * 24 * N + (12 + i) * N + k] = sf;    // MPC.cpp:574
+      outp[i * N + k] = sx;           // retrieve_result, MPC.cpp:573
+      outp[(12 + i) * N + k] = sf;    // MPC.cpp:574
     }
   }
   // back to OSQP's scaled iterates for the persistent state
@@ -1135,8 +1265,19 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     a.pri[b] = pri_res;
     a.dua[b] = dua_res;
     a.rho_updates[b] = rho_updates;
+    if (SEQ && a.seq_iters) a.seq_iters[io] = iter;
+#ifdef QRW_SEQ_STATS  // diagnostics: duration of this task in 100 MHz ticks (a.prof holds 10 doubles per instance: K <= 5)
+    if (a.prof && a.seq_K <= 5) {
+      a.prof[io * 2] = (double)(__builtin_amdgcn_s_memrealtime() - task_t0);
+      a.prof[io * 2 + 1] = (double)iter;
+    }
+#endif
   }
   }
+  }  // set up
+  if constexpr (SEQ) seq_finish_task<NW>(a, b, seq_s, tid);
+  else break;
+  }  // task loop
 #undef QRW_UNPARK
 #undef ST
 }
@@ -1175,12 +1316,82 @@ int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// true for builds made with a timing-experiment macro: they compute wrong results on purpose, the self-test is skipped
+bool mpc_build_is_timing_experiment() {
+#if defined(QRW_EXPERIMENT_NOTERM) || defined(QRW_EXPERIMENT_NODEP)
+  return true;
+#else
+  return false;
+#endif
+}
+
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {
   if (a.N < 1 || a.N > kMpcMaxN) return -1;
-  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true>), dim3(a.B), dim3(64), 0, stream, a);
-  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false>), dim3(a.B), dim3(64), 0, stream, a);
-  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true>), dim3(a.B), dim3(128), 0, stream, a);
-  else hipLaunchKernelGGL((mpc_solve_kernel<2, false>), dim3(a.B), dim3(128), 0, stream, a);
+  const MpcArgs* none = nullptr;
+  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, false>), dim3(a.B), dim3(64), 0, stream, a, none);
+  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, false>), dim3(a.B), dim3(64), 0, stream, a, none);
+  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false>), dim3(a.B), dim3(128), 0, stream, a, none);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false>), dim3(a.B), dim3(128), 0, stream, a, none);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// queues of a sequence.  Ranks in the handle's longest-first order decide the level of an instance (cut[] below; everything
+// in the lowest level when there is no order yet).  Call 0 of the first
+// `groups` ranks is dealt by workgroup index (first[]), the other call-0 tasks are queued in rank order.  One block.
+__global__ void mpc_seq_init_kernel(int* queue, unsigned* qctr, int* level, int* first, const int* order, int B, int K, int groups) {
+  __shared__ unsigned n_lvl[kSeqLevels], base[kSeqLevels], n_q[kSeqLevels], n_dealt[kSeqLevels];
+  const int cut[kSeqLevels] = {B / 16, B / 4, B / 2, B};  // eight finer levels measured slower (748 k against 768 k solves/s)
+  auto level_of = [&](int rank) {
+    if (!order) return kSeqLevels - 1;
+    for (int l = 0; l < kSeqLevels; l++) if (rank < cut[l]) return l;
+    return kSeqLevels - 1;
+  };
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int l = 0; l < kSeqLevels; l++) {
+      const int lo = (l == 0) ? 0 : cut[l - 1];
+      n_lvl[l] = order ? (unsigned)(cut[l] - lo) : (l == kSeqLevels - 1 ? (unsigned)B : 0u);
+      base[l] = run;
+      run += n_lvl[l] * (unsigned)K;
+      n_q[l] = 0;
+      n_dealt[l] = 0;
+    }
+  }
+  __syncthreads();
+  for (long i = threadIdx.x; i < (long)B * K; i += blockDim.x) queue[i] = -1;
+  __syncthreads();
+  for (int r = threadIdx.x; r < B; r += blockDim.x) {
+    const int b = order ? order[r] : r;
+    const int l = level_of(r);
+    level[b] = l;
+    if (r < groups) first[r] = b;  // call 0 of instance b goes straight to workgroup r
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the remaining call-0 tasks, in rank order, into their levels' queues (serial: B - groups entries)
+    for (int r = 0; r < B; r++) {
+      const int l = level_of(r);
+      if (r < groups) n_dealt[l]++;
+      else queue[base[l] + n_q[l]++] = order ? order[r] : r;
+    }
+    for (int l = 0; l < kSeqLevels; l++) {
+      qctr[l * kSeqStride] = 0u;
+      qctr[l * kSeqStride + 1] = n_q[l];
+      qctr[kSeqErr + 2 + l] = n_lvl[l] * (unsigned)K - n_dealt[l];
+      qctr[kSeqErr + 16 + l] = base[l];
+    }
+    qctr[kSeqErr] = 0u;
+    qctr[kSeqErr + 1] = 0u;
+  }
+}
+
+// a_mem: a copy of `a` in device memory that stays valid until the launch has finished (the kernel re-reads it per task)
+int mpc_sequence_launch(const MpcArgs& a, const MpcArgs* a_mem, int groups, hipStream_t stream) {
+  if (a.N < 1 || a.N > kMpcMaxN || a.seq_K < 1 || !a.queue || !a.qctr || !a.seq_hot || !a.seq_first || !a_mem) return -1;
+  hipLaunchKernelGGL(mpc_seq_init_kernel, dim3(1), dim3(1024), 0, stream, a.queue, a.qctr, a.seq_hot, a.seq_first, a.order, a.B, a.seq_K, groups);
+  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, true>), dim3(groups), dim3(64), 0, stream, a, a_mem);
+  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, true>), dim3(groups), dim3(64), 0, stream, a, a_mem);
+  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, true>), dim3(groups), dim3(128), 0, stream, a, a_mem);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, true>), dim3(groups), dim3(128), 0, stream, a, a_mem);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -44,6 +44,15 @@ struct qrw_handle_s {
   float* mpc_ema = nullptr;  // moving average of each instance's iteration counts (longest-first block order)
   bool mpc_have_order = false;
   double *mpc_rho = nullptr, *mpc_pri = nullptr, *mpc_dua = nullptr, *mpc_prof = nullptr;
+  // sequences (qrw_mpc_solve_sequence): task queue, counters, argument block re-read by the persistent kernel
+  int* seq_queue = nullptr;
+  size_t seq_queue_len = 0;
+  unsigned* seq_ctr = nullptr;
+  int* seq_hot = nullptr;
+  int* seq_first = nullptr;
+  qrw::MpcArgs* seq_args = nullptr;
+  qrw::MpcArgs seq_args_host;
+  int seq_groups = 0;
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -167,6 +176,10 @@ static int mpc_known_answer_check(double* worst) {
 static int g_kat_state[64] = {0};  // per device: 0 not run, 1 passed, -1 failed
 static int mpc_known_answer_once(int device) {
   if (device < 0 || device >= 64) return 0;
+  if (g_kat_state[device] == 0 && qrw::mpc_build_is_timing_experiment()) {
+    fprintf(stderr, "libqrw_hip: TIMING-EXPERIMENT BUILD (wrong results by construction), self-test skipped\n");
+    g_kat_state[device] = 1;
+  }
   if (g_kat_state[device] == 0) {
     double w = 0.0;
     const int rc = mpc_known_answer_check(&w);
@@ -238,6 +251,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_ema); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
   hipFree(h->plan_st); hipFree(h->ctrl_st);
+  hipFree(h->seq_queue); hipFree(h->seq_ctr); hipFree(h->seq_args); hipFree(h->seq_hot); hipFree(h->seq_first);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -254,6 +268,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   if (!h || !d_xref || !d_fsteps || !d_out) return fail(-1, "qrw_mpc_solve: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   qrw::MpcArgs a;
+  memset(&a, 0, sizeof(a));
   a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
   a.xref = d_xref; a.fsteps = d_fsteps; a.num_iter = d_num_iter; a.num_iter_scalar = num_iter_scalar;
   a.out = d_out; a.st = h->mpc_st; a.gait = h->mpc_gait; a.flags = h->mpc_flags; a.iters = h->mpc_iters;
@@ -286,6 +301,68 @@ extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const doub
   int rc = qrw_mpc_solve(h, dx, df, h_num_iter ? h->stage_i : nullptr, num_iter_scalar, dout, nullptr);
   if (rc) return rc;
   HIP_OK(hipMemcpy(h_out, dout, B * 24 * N * sizeof(double), hipMemcpyDeviceToHost), "D2H result");
+  return 0;
+}
+
+extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_xref, const double* d_fsteps, int32_t first_num_iter,
+                                      double* d_out, int32_t* d_iters, void* stream) {
+  if (!h || !d_xref || !d_fsteps || !d_out || K < 1) return fail(-1, "qrw_mpc_solve_sequence: bad argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  const size_t need = (size_t)K * (size_t)h->cfg.batch;
+  if (need > (size_t)0x7fffffff) return fail(-1, "qrw_mpc_solve_sequence: K * batch too large");
+  if (need > h->seq_queue_len) {  // grown on demand (first call / longer sequence), never on a steady-state call
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream), "qrw_mpc_solve_sequence sync");
+    hipFree(h->seq_queue);
+    h->seq_queue = nullptr;
+    h->seq_queue_len = 0;
+    if (hipMalloc((void**)&h->seq_queue, need * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc queue");
+    h->seq_queue_len = need;
+  }
+  if (!h->seq_ctr) {
+    if (hipMalloc((void**)&h->seq_ctr, qrw::kSeqQctrWords * sizeof(unsigned)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc counters");
+    if (hipMalloc((void**)&h->seq_first, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc first tasks");
+    if (hipMalloc((void**)&h->seq_hot, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc hot flags");
+    if (hipMalloc((void**)&h->seq_args, sizeof(qrw::MpcArgs)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc args");
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device), "hipGetDeviceProperties");
+    // resident workgroups: one 512-register wavefront per SIMD (N <= 16: 4 workgroups per CU; N > 16: 2 of two wavefronts)
+    h->seq_groups = prop.multiProcessorCount * (h->cfg.n_steps <= 16 ? 4 : 2);
+  }
+  qrw::MpcArgs& a = h->seq_args_host;
+  memset(&a, 0, sizeof(a));
+  a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
+  a.xref = d_xref; a.fsteps = d_fsteps; a.num_iter = nullptr; a.num_iter_scalar = first_num_iter;
+  a.out = d_out; a.st = h->mpc_st; a.gait = h->mpc_gait; a.flags = h->mpc_flags; a.iters = h->mpc_iters;
+  a.status = h->mpc_status; a.rho_out = h->mpc_rho; a.pri = h->mpc_pri; a.dua = h->mpc_dua;
+  a.rho_updates = h->mpc_rho_updates;
+  a.prof = h->mpc_prof;  // only diagnostic builds (-DQRW_SEQ_STATS) write it
+  a.order = h->mpc_have_order ? h->mpc_order : nullptr;
+  a.seq_K = K; a.queue = h->seq_queue; a.qctr = h->seq_ctr; a.seq_hot = h->seq_hot; a.seq_first = h->seq_first; a.seq_iters = d_iters;
+  HIP_OK(hipMemcpyAsync(h->seq_args, &a, sizeof(a), hipMemcpyHostToDevice, (hipStream_t)stream), "qrw_mpc_solve_sequence args");
+  const int groups = h->seq_groups < h->cfg.batch ? h->seq_groups : h->cfg.batch;
+  if (qrw::mpc_sequence_launch(a, h->seq_args, groups, (hipStream_t)stream) != 0)
+    return fail(-11, "qrw_mpc_solve_sequence: kernel launch failed", hipGetLastError());
+  if (h->cfg.batch > 1024) {
+    if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_ema, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
+      return fail(-11, "qrw_mpc_solve_sequence: order kernel launch failed", hipGetLastError());
+    h->mpc_have_order = true;
+  }
+  return 0;
+}
+
+extern "C" int qrw_mpc_sequence_error(qrw_handle h, int32_t* timed_out) {
+  if (!h || !timed_out) return fail(-1, "qrw_mpc_sequence_error: null argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  *timed_out = 0;
+  if (!h->seq_ctr) return 0;
+  unsigned c[qrw::kSeqQctrWords];
+  HIP_OK(hipMemcpy(c, h->seq_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_sequence_error");
+  *timed_out = (int32_t)c[qrw::kSeqErrWord];
+  if (getenv("QRW_SEQ_STATS")) {
+    fprintf(stderr, "qrw sequence: levels taken/queued");
+    for (int l = 0; l < qrw::kSeqErrWord / 16; l++) fprintf(stderr, " %u/%u", c[16 * l], c[16 * l + 1]);
+    fprintf(stderr, ", looking-for-work ticks (100 MHz, summed) %u\n", c[qrw::kSeqErrWord + 1]);
+  }
   return 0;
 }
 

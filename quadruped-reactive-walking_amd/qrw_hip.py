@@ -47,6 +47,8 @@ SIGNATURES = {
     "qrw_mpc_solve_host": (C.c_int, [_vp, _dp, _dp, _ip, C.c_int32, _dp]),
     "qrw_mpc_get_gait": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "qrw_mpc_copy_iters": (C.c_int, [_vp, _vp, _vp]),
+    "qrw_mpc_solve_sequence": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "qrw_mpc_sequence_error": (C.c_int, [_vp, _ip]),
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
@@ -234,6 +236,31 @@ class Batch:
             self._dev(out["ddq_res"], (B, 6)), self._dev(out["feet"], (B, 3, 3, 4)), self._stream()),
             "qrw_wbc_compute")
         return out
+
+    def mpc_solve_sequence(self, xref, fsteps, first_num_iter=0, out=None, iters=None):
+        """K consecutive MPC calls of every instance in one launch, ordered per instance only (qrw_mpc_solve_sequence):
+        xref (K,B,12,N+1), fsteps (K,B,N_gait,12) CUDA float64 -> out (K,B,24,N); iters: optional CUDA int32 (K,B)."""
+        import torch
+
+        K = int(xref.shape[0])
+        if out is None:
+            out = torch.empty((K, self.B, 24, self.N), dtype=torch.float64, device=xref.device)
+        ip = _vp(0)
+        if iters is not None:
+            if not (iters.is_cuda and iters.dtype == torch.int32 and iters.is_contiguous() and tuple(iters.shape) == (K, self.B)):
+                raise QrwError("iters must be a contiguous CUDA int32 tensor of shape (K, B)")
+            ip = _vp(iters.data_ptr())
+        _check(self._lib.qrw_mpc_solve_sequence(self._handle, K, self._dev(xref, (K, self.B, 12, self.N + 1)),
+                                                self._dev(fsteps, (K, self.B, self.N_gait, 12)), int(first_num_iter),
+                                                self._dev(out, (K, self.B, 24, self.N)), ip, self._stream()),
+               "qrw_mpc_solve_sequence")
+        return out
+
+    def mpc_sequence_timed_out(self):
+        """After synchronising: True if the sequence kernel's task queue ever gave up waiting (never expected)."""
+        v = C.c_int32(0)
+        _check(self._lib.qrw_mpc_sequence_error(self._handle, C.byref(v)), "qrw_mpc_sequence_error")
+        return bool(v.value)
 
     def copy_mpc_iters(self, dst):
         """Last solve's ADMM iteration counts -> CUDA int32 tensor (B,), device to device on the current stream."""

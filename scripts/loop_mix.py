@@ -17,7 +17,7 @@ def cls(op):
 hdr = [i for i, l in enumerate(L) if "Loop Header: Depth=1" in l and "Child Loop" in L[i + 1]][0]
 tgt = None
 for i in range(hdr, hdr + 30):
-    m = re.search(r"s_cbranch_execz (\.LBB2_\d+)", L[i])
+    m = re.search(r"s_cbranch_execz (\.LBB\d+_\d+)", L[i])
     if m: tgt = m.group(1); break
 start = [i for i, l in enumerate(L) if l.startswith(tgt + ":")][0]
 end = [i for i, l in enumerate(L) if "s_cbranch_scc0" in l and i > start][0]

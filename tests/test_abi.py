@@ -79,7 +79,7 @@ def test_shipped_mpc_kernel_spills_nothing_to_scratch():
                         "-Rpass-analysis=kernel-resource-usage"] + mpcflags +
                        [os.path.join(csrc, "mpc_kernel.hip"), "-o", os.devnull], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    blk = r.stderr.split("mpc_solve_kernelILi1ELb1E")[1]
+    blk = r.stderr.split("mpc_solve_kernelILi1ELb1ELb0E")[1]
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
     agprs = int(re.search(r"AGPRs: (\d+)", blk).group(1))
     vspill = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))

@@ -354,3 +354,45 @@ def test_wide_oracle_parity_sample(oracle_mod, synth_mod, N, gaits, B):
         assert e < RTOL, (s, e)
     assert 1 in seen_status
     print("wide parity N=%d B=%d: worst relative deviation %.2e, statuses %s" % (N, B, worst, sorted(seen_status)))
+
+
+@pytest.mark.parametrize("N,B,K,gaits", [(16, 8, 5, ("trot",)), (16, 1500, 6, ("trot", "walk")), (12, 40, 4, ("trot",)),
+                                         (32, 24, 4, ("walk", "trot", "bounding")), (24, 10, 3, ("trot",))])
+def test_sequence_launch_equals_consecutive_calls(synth_mod, N, B, K, gaits):
+    """qrw_mpc_solve_sequence (persistent workgroups, per-instance task queue, no device-wide barrier between the calls)
+    must give what K calls of qrw_mpc_solve give, bit for bit: every call's result, iteration counts, statuses of the last
+    call and the warm-start state it leaves behind (checked through one more ordinary call on both handles)."""
+    import torch
+
+    import qrw_hip
+
+    N_gait = max(20, N + 4)
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, seed0=20280000 + N)
+    steps = [sb.step(s) for s in range(K + 1)]
+    a, b = (qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N) for _ in range(2))
+    dev = torch.device("cuda", 0)
+    xs = torch.from_numpy(np.stack([st["xref"] for st in steps[:K]])).to(dev)
+    fs = torch.from_numpy(np.stack([st["fsteps"] for st in steps[:K]])).to(dev)
+    ref_out, ref_it = [], []
+    for s in range(K):
+        ref_out.append(a.mpc_solve(xs[s], fs[s], s).cpu().numpy())
+        ref_it.append(a.mpc_stats()["iters"].copy())
+    its = torch.zeros((K, B), dtype=torch.int32, device=dev)
+    out = b.mpc_solve_sequence(xs, fs, 0, iters=its)
+    torch.cuda.synchronize()
+    assert not b.mpc_sequence_timed_out()
+    assert np.array_equal(its.cpu().numpy(), np.stack(ref_it))
+    assert np.array_equal(out.cpu().numpy(), np.stack(ref_out))
+    sa, sb_ = a.mpc_stats(), b.mpc_stats()
+    for key in ("iters", "status"):
+        assert np.array_equal(sa[key], sb_[key]), key
+    assert np.array_equal(sa["rho"], sb_["rho"])
+    # the state left behind: one more ordinary call on both
+    x1 = torch.from_numpy(steps[K]["xref"]).to(dev)
+    f1 = torch.from_numpy(steps[K]["fsteps"]).to(dev)
+    assert np.array_equal(a.mpc_solve(x1, f1, K).cpu().numpy(), b.mpc_solve(x1, f1, K).cpu().numpy())
+    # a second sequence continuing from there (first_num_iter > 0) against ordinary calls
+    o2 = b.mpc_solve_sequence(xs[:2].contiguous(), fs[:2].contiguous(), K + 1)
+    r2 = [a.mpc_solve(xs[s], fs[s], K + 1 + s).cpu().numpy() for s in range(2)]
+    torch.cuda.synchronize()
+    assert np.array_equal(o2.cpu().numpy(), np.stack(r2)) and not b.mpc_sequence_timed_out()
