@@ -395,9 +395,7 @@ __device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long lon
   int task = -1;
   if (tid == 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    if (first_pass) {  // dealt by workgroup index (the init kernel left these out of the queues)
-      task = ((int)blockIdx.x < a.B) ? a.seq_first[blockIdx.x] : -1;
-    }
+    if (first_pass) task = a.seq_first[blockIdx.x];  // dealt by workgroup index (the init kernel left these out of the queues)
     bool give_up = first_pass;
     while (task < 0 && !give_up) {
       bool all_done = true;
@@ -469,35 +467,24 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // SEQ = true:  persistent workgroups work through K consecutive calls of every instance (qrw_mpc_solve_sequence): tasks
 //   (call s, instance b) come from a queue in global memory; a task is queued when its predecessor (s-1, b) has finished,
 //   so the only ordering is per instance and one instance's long solve delays nobody else's next call.
-//   The sequence form reads its argument block from memory at the start of every task and derives the per-lane constants
-//   anew (both behind an opaque asm), so that nothing but a pointer and the thread id is live across tasks: hoisted out
-//   of the task loop they cost 140 spilled SGPRs and 364 B of scratch per lane.
+//   One task per workgroup: the sequence launch has K * B workgroups and the hardware starts a new one whenever a
+//   resident one ends, exactly as in the one-call launch.  (A first version kept persistent workgroups in a task loop; with
+//   the loop around it the body was compiled with 42-140 spilled SGPRs and 364 B of scratch per lane and ran 5 % slower per
+//   ADMM iteration.  Without the loop the two forms compile alike.)
 template <int NW, bool FULL, bool SEQ>
-__global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a_in, const MpcArgs* a_mem) {
+__global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   __shared__ MpcLdsT<NW> L;
   constexpr int T = 64 * NW;  // threads per instance
   // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
   // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
   PH_DECL
-  bool seq_first_pass = true;
-  for (;;) {  // SEQ: one task per pass; otherwise a single pass
-  int tid = threadIdx.x;
-  MpcArgs a_task;
-  if constexpr (SEQ) {
-    const MpcArgs* q = a_mem;
-    asm volatile("" : "+s"(q), "+v"(tid));
-    a_task = *q;
-  }
-  const MpcArgs& a = SEQ ? a_task : a_in;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-#ifdef QRW_SEQ_STATS
-  const unsigned long long task_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  {
   int b, seq_s = 0;
   if constexpr (SEQ) {
-    const int task = seq_next_task<NW>(a, &L.sBal[0], tid, seq_first_pass);
-    seq_first_pass = false;
-    if (task < 0) return;  // every task has been handed out (or the queue timed out: a.qctr[2] is set)
+    const int task = seq_next_task<NW>(a, &L.sBal[0], tid, (int)blockIdx.x < a.seq_groups);
+    if (task < 0) return;  // the queue timed out (the error flag in a.qctr is set)
     seq_s = task / a.B;
     b = task - seq_s * a.B;
   } else {
@@ -1276,8 +1263,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a_in, con
   }
   }  // set up
   if constexpr (SEQ) seq_finish_task<NW>(a, b, seq_s, tid);
-  else break;
-  }  // task loop
+  }
 #undef QRW_UNPARK
 #undef ST
 }
@@ -1327,11 +1313,10 @@ bool mpc_build_is_timing_experiment() {
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {
   if (a.N < 1 || a.N > kMpcMaxN) return -1;
-  const MpcArgs* none = nullptr;
-  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, false>), dim3(a.B), dim3(64), 0, stream, a, none);
-  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, false>), dim3(a.B), dim3(64), 0, stream, a, none);
-  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false>), dim3(a.B), dim3(128), 0, stream, a, none);
-  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false>), dim3(a.B), dim3(128), 0, stream, a, none);
+  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, false>), dim3(a.B), dim3(64), 0, stream, a);
+  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, false>), dim3(a.B), dim3(64), 0, stream, a);
+  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false>), dim3(a.B), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false>), dim3(a.B), dim3(128), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1384,14 +1369,16 @@ __global__ void mpc_seq_init_kernel(int* queue, unsigned* qctr, int* level, int*
   }
 }
 
-// a_mem: a copy of `a` in device memory that stays valid until the launch has finished (the kernel re-reads it per task)
-int mpc_sequence_launch(const MpcArgs& a, const MpcArgs* a_mem, int groups, hipStream_t stream) {
-  if (a.N < 1 || a.N > kMpcMaxN || a.seq_K < 1 || !a.queue || !a.qctr || !a.seq_hot || !a.seq_first || !a_mem) return -1;
-  hipLaunchKernelGGL(mpc_seq_init_kernel, dim3(1), dim3(1024), 0, stream, a.queue, a.qctr, a.seq_hot, a.seq_first, a.order, a.B, a.seq_K, groups);
-  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, true>), dim3(groups), dim3(64), 0, stream, a, a_mem);
-  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, true>), dim3(groups), dim3(64), 0, stream, a, a_mem);
-  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, true>), dim3(groups), dim3(128), 0, stream, a, a_mem);
-  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, true>), dim3(groups), dim3(128), 0, stream, a, a_mem);
+// one workgroup per task: K * B workgroups, of which the device keeps `a.seq_groups` resident at a time
+int mpc_sequence_launch(const MpcArgs& a, hipStream_t stream) {
+  if (a.N < 1 || a.N > kMpcMaxN || a.seq_K < 1 || !a.queue || !a.qctr || !a.seq_hot || !a.seq_first || a.seq_groups < 1) return -1;
+  hipLaunchKernelGGL(mpc_seq_init_kernel, dim3(1), dim3(1024), 0, stream, a.queue, a.qctr, a.seq_hot, a.seq_first, a.order, a.B, a.seq_K,
+                     a.seq_groups);
+  const unsigned tasks = (unsigned)a.seq_K * (unsigned)a.B;
+  if (a.N == 16) hipLaunchKernelGGL((mpc_solve_kernel<1, true, true>), dim3(tasks), dim3(64), 0, stream, a);
+  else if (a.N < 16) hipLaunchKernelGGL((mpc_solve_kernel<1, false, true>), dim3(tasks), dim3(64), 0, stream, a);
+  else if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, true>), dim3(tasks), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, true>), dim3(tasks), dim3(128), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -50,8 +50,6 @@ struct qrw_handle_s {
   unsigned* seq_ctr = nullptr;
   int* seq_hot = nullptr;
   int* seq_first = nullptr;
-  qrw::MpcArgs* seq_args = nullptr;
-  qrw::MpcArgs seq_args_host;
   int seq_groups = 0;
   // WBC
   double* wbc_st = nullptr;
@@ -251,7 +249,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_ema); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
   hipFree(h->plan_st); hipFree(h->ctrl_st);
-  hipFree(h->seq_queue); hipFree(h->seq_ctr); hipFree(h->seq_args); hipFree(h->seq_hot); hipFree(h->seq_first);
+  hipFree(h->seq_queue); hipFree(h->seq_ctr); hipFree(h->seq_hot); hipFree(h->seq_first);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -322,13 +320,12 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
     if (hipMalloc((void**)&h->seq_ctr, qrw::kSeqQctrWords * sizeof(unsigned)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc counters");
     if (hipMalloc((void**)&h->seq_first, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc first tasks");
     if (hipMalloc((void**)&h->seq_hot, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc hot flags");
-    if (hipMalloc((void**)&h->seq_args, sizeof(qrw::MpcArgs)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc args");
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device), "hipGetDeviceProperties");
     // resident workgroups: one 512-register wavefront per SIMD (N <= 16: 4 workgroups per CU; N > 16: 2 of two wavefronts)
     h->seq_groups = prop.multiProcessorCount * (h->cfg.n_steps <= 16 ? 4 : 2);
   }
-  qrw::MpcArgs& a = h->seq_args_host;
+  qrw::MpcArgs a;
   memset(&a, 0, sizeof(a));
   a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
   a.xref = d_xref; a.fsteps = d_fsteps; a.num_iter = nullptr; a.num_iter_scalar = first_num_iter;
@@ -338,9 +335,8 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
   a.prof = h->mpc_prof;  // only diagnostic builds (-DQRW_SEQ_STATS) write it
   a.order = h->mpc_have_order ? h->mpc_order : nullptr;
   a.seq_K = K; a.queue = h->seq_queue; a.qctr = h->seq_ctr; a.seq_hot = h->seq_hot; a.seq_first = h->seq_first; a.seq_iters = d_iters;
-  HIP_OK(hipMemcpyAsync(h->seq_args, &a, sizeof(a), hipMemcpyHostToDevice, (hipStream_t)stream), "qrw_mpc_solve_sequence args");
-  const int groups = h->seq_groups < h->cfg.batch ? h->seq_groups : h->cfg.batch;
-  if (qrw::mpc_sequence_launch(a, h->seq_args, groups, (hipStream_t)stream) != 0)
+  a.seq_groups = h->seq_groups < h->cfg.batch ? h->seq_groups : h->cfg.batch;
+  if (qrw::mpc_sequence_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_mpc_solve_sequence: kernel launch failed", hipGetLastError());
   if (h->cfg.batch > 1024) {
     if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_ema, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)

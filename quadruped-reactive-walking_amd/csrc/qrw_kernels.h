@@ -63,6 +63,7 @@ struct MpcArgs {
   unsigned* qctr;    // [kSeqQctrWords] per-level heads / tails, error flag, level sizes and bases (mpc_kernel.hip)
   int* seq_hot;      // [B] priority level of each instance (0 = longest chains)
   int* seq_first;    // [B] call-0 tasks dealt by workgroup index
+  int seq_groups;    // workgroups resident at a time = call-0 tasks dealt by index
   int* seq_iters;    // optional [seq_K][B]
 };
 
@@ -70,7 +71,7 @@ int mpc_launch(const MpcArgs& a, hipStream_t stream);
 bool mpc_build_is_timing_experiment();
 constexpr int kSeqErrWord = 4 * 16;              // kSeqLevels * kSeqStride: the error flag's word in qctr (mpc_kernel.hip)
 constexpr int kSeqQctrWords = kSeqErrWord + 32;  // + error / diagnostics / level totals / level bases
-int mpc_sequence_launch(const MpcArgs& a, const MpcArgs* a_mem, int groups, hipStream_t stream);
+int mpc_sequence_launch(const MpcArgs& a, hipStream_t stream);
 int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_t stream);
 
 // WBC persistent state: st[instance][item]
