@@ -396,7 +396,7 @@ def stream_groups_figure(B, N, N_gait, dev, W, K, data, S=2):
 
 def pipelined_sequence_figure(B, N, N_gait, dev, W, K, data):
     """The headline's K timed steps (same inputs, bit-identical results) submitted as ONE qrw_mpc_solve_sequence launch —
-    persistent workgroups, a task queue that orders each instance's consecutive solves and nothing else — followed by the
+    one workgroup per task, task queues that orders each instance's consecutive solves and nothing else — followed by the
     K WBC steps.  Legitimate only where all K steps' inputs exist beforehand (log replay, open-loop sweeps: the headline's
     open-loop sequence is such a case, a closed control loop is not), hence a secondary figure: it shows what the
     device-wide barrier between the steps of independent robots costs (the launch tail of DESIGN.md 4.1)."""

@@ -464,7 +464,7 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 
 // FULL: N == 16 * NW, every lane owns a live horizon step (the masks on `act` fold away)
 // SEQ = false: one workgroup solves one instance's one MPC call (qrw_mpc_solve).
-// SEQ = true:  persistent workgroups work through K consecutive calls of every instance (qrw_mpc_solve_sequence): tasks
+// SEQ = true:  K * B workgroups (one task each) work through K consecutive calls of every instance (qrw_mpc_solve_sequence): tasks
 //   (call s, instance b) come from a queue in global memory; a task is queued when its predecessor (s-1, b) has finished,
 //   so the only ordering is per instance and one instance's long solve delays nobody else's next call.
 //   One task per workgroup: the sequence launch has K * B workgroups and the hardware starts a new one whenever a

@@ -359,7 +359,7 @@ def test_wide_oracle_parity_sample(oracle_mod, synth_mod, N, gaits, B):
 @pytest.mark.parametrize("N,B,K,gaits", [(16, 8, 5, ("trot",)), (16, 1500, 6, ("trot", "walk")), (12, 40, 4, ("trot",)),
                                          (32, 24, 4, ("walk", "trot", "bounding")), (24, 10, 3, ("trot",))])
 def test_sequence_launch_equals_consecutive_calls(synth_mod, N, B, K, gaits):
-    """qrw_mpc_solve_sequence (persistent workgroups, per-instance task queue, no device-wide barrier between the calls)
+    """qrw_mpc_solve_sequence (one workgroup per task, per-instance task queues, no device-wide barrier between the calls)
     must give what K calls of qrw_mpc_solve give, bit for bit: every call's result, iteration counts, statuses of the last
     call and the warm-start state it leaves behind (checked through one more ordinary call on both handles)."""
     import torch
