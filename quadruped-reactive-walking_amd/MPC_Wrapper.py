@@ -187,6 +187,16 @@ class MPC_Wrapper_batch:
         self._out = self._b.mpc_solve(xref, fsteps, k, out=self._out)
         return 0
 
+    def replay_batch(self, k0, xref_log, fsteps_log, out=None):
+        """Recompute `mpc_x_f` for logged planner outputs: xref_log (K,B,12,N+1), fsteps_log (K,B,N_gait,12) as
+        `LoggerControl` records them (`planner_xref`, `planner_fsteps`, scripts/LoggerControl.py:61-65,142-143) ->
+        (K,B,24,N) (`mpc_x_f`, :76,:152).  Same results as K calls of solve_batch(k0 + s, ...), but one launch ordered per
+        instance only (qrw_mpc_solve_sequence); for inputs known beforehand, not for a closed loop.  The last call's
+        result becomes the latest result."""
+        res = self._b.mpc_solve_sequence(xref_log, fsteps_log, k0, out=out)
+        self._out = res[-1]
+        return res
+
     def get_latest_result_batch(self):
         """scripts/MPC_Wrapper.py:106-126, synchronous branch: the first call returns the default forces."""
         if self.not_first_iter:

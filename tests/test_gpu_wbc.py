@@ -269,3 +269,28 @@ def test_config4_batch4096_n32_mixed_gaits_properties(oracle_mod, synth_mod):
             assert st["iters"][j] == refs[j].iter and rel_err(o2[j], refs[j].get_latest_result()) < RTOL
     assert np.array_equal(o2, out[idx])
     assert len(set(sb.kind[idx].tolist())) >= 2  # the spread covers more than one gait
+
+
+def test_replay_batch_equals_solve_batch_calls(synth_mod):
+    """MPC_Wrapper_batch.replay_batch (logged planner outputs -> mpc_x_f in one launch) against solve_batch call by call."""
+    import torch
+
+    import MPC_Wrapper
+
+    B, N, K = 37, 16, 5
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=99100)
+    steps = [sb.step(s) for s in range(K)]
+    xs = torch.from_numpy(np.stack([st["xref"] for st in steps])).cuda()
+    fs = torch.from_numpy(np.stack([st["fsteps"] for st in steps])).cuda()
+    a = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B)
+    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B)
+    ref = []
+    for s in range(K):
+        a.solve_batch(s, xs[s], fs[s])
+        a.get_latest_result_batch()
+        ref.append(a.get_latest_result_batch().cpu().numpy().copy())
+    got = b.replay_batch(0, xs, fs)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), np.stack(ref))
+    b.get_latest_result_batch()
+    assert np.array_equal(b.get_latest_result_batch().cpu().numpy(), ref[-1])
