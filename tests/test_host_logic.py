@@ -94,3 +94,28 @@ def test_mpc_wrapper_default_result_bookkeeping(synth_mod):
                         if last[i] == 1:
                             exp[12 + 3 * i + 2, 15] = 9.81 * 2.5 / last.sum()
             assert np.array_equal(w.last_available_result, exp), (name, k)
+
+
+def test_bench_work_terms_follow_the_survey_contract():
+    """bench.py's algorithmic work per unit: 64.8 kflop per ADMM iteration, 0.33 Mflop per factorisation and
+    36.4 KB per control step at N = 16, and the N-dependence scripts/alg_work.py derives by symbolic factorisation."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    bench = load("bench_mod", os.path.join(root, "bench.py"))
+    alg = load("alg_work_mod", os.path.join(root, "scripts", "alg_work.py"))
+    assert bench.f_iter(16) == 4 * 10946 + 4 * 1998 + 12 * 1088 == 64832.0
+    assert abs(bench.f_fac(16) - 0.33e6) < 1e-6 and abs(bench.b_alg(16, 20) - 36.4e3) < 100
+    assert bench.f_iter(32) == 4 * (726 * 32 - 670) + 4 * (126 * 32 - 18) + 12 * 68 * 32
+    nnzL, f_fac, nnzA = alg.symbolic(8)  # below-diagonal entries of the symbolic factor, N = 8
+    assert nnzA == 126 * 8 - 18
+    assert abs((nnzL + 24 * 8) - (726 * 8 - 670)) <= 12  # the linear form is anchored on the survey's 10 946 at N = 16
+    assert abs(bench.f_fac(8) / bench.f_fac(16) - f_fac / alg.symbolic(16)[1]) < 0.02
