@@ -6,14 +6,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, torch
 import qrw_hip, synth
-B, N, W, K = 4096, 16, 4, 20
-sb = synth.SyntheticBatch(B, N, N_gait=20, gaits=("trot",), n_seq=W + K)
+B, N, W, K = 4096, int(os.environ.get("QRW_EXP_N", "16")), 4, int(os.environ.get("QRW_EXP_K", "20"))
+NG = max(20, N + 4)
+sb = synth.SyntheticBatch(B, N, N_gait=NG, gaits=("trot",) if N <= 16 else ("walk", "trot", "bounding"), n_seq=W + K)
 steps = [sb.step(s) for s in range(W + K)]
 dev = torch.device("cuda", 0)
 keys = ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     Bs = B // S
-    engs = [qrw_hip.Batch(Bs, n_steps=N, N_gait=20) for _ in range(S)]
+    engs = [qrw_hip.Batch(Bs, n_steps=N, N_gait=NG, T_gait=0.02 * N) for _ in range(S)]
     if os.environ.get("QRW_EXP_OWN_STREAMS") == "1":
         own = [qrw_hip.CuStream(0, 0, 0) for _ in range(S)]  # hipStreamCreateWithFlags(hipStreamNonBlocking), one each
         streams = [o.torch for o in own]
