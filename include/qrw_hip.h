@@ -105,6 +105,12 @@ int qrw_mpc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double 
 int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double *h_y, double *h_D, double *h_E,
                       double *h_c);
 
+/* Diagnostic: the block order the NEXT qrw_mpc_solve will use (h_order[i] = instance solved by workgroup i: a
+ * permutation of 0..B-1, longest predicted solve first) and the moving average of iteration counts it was sorted by
+ * (either may be NULL).  *has_order = 0 while no order exists (batch <= 1024, or before the first solve).  Synchronises
+ * the device.  No reference counterpart (scheduling only; results do not depend on it).  Tests only. */
+int qrw_mpc_get_order(qrw_handle h, int32_t *h_order, float *h_ema, int32_t *has_order);
+
 /* Replaces wbc_controller.compute (scripts/QP_WBC.py:52-131) with everything it calls:
  * Solo12InvKin.refreshAndCompute (scripts/solo12InvKin.py:44-69), InvKin::refreshAndCompute
  * (src/InvKin.cpp:23-73), the Pinocchio crba/Jacobian/rnea calls (QP_WBC.py:89-116) and

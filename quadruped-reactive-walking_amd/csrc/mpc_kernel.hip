@@ -1268,37 +1268,96 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #undef ST
 }
 
-// Counting sort of the instances by decreasing iteration count (multiples of 25, at most 4000) -> order[]
-__global__ __launch_bounds__(1024) void mpc_order_kernel(const int* iters, float* ema, int* order, int B) {
+// Counting sort of the instances by decreasing iteration count (multiples of 25, at most 4000) -> order[].
+// ONE wavefront: while other solves are resident (a second stream group, the asynchronous mode) every SIMD is owned by a
+// 512-register solve wavefront; the 16-wavefront workgroup this used to be waited for a whole compute unit to drain
+// (measured: up to 4 ms in the two-stream-group run, and the same with 4 wavefronts: a workgroup's wavefronts are spread
+// over the SIMDs), one wavefront takes the first SIMD that frees.  To stay short alone it reads 16 instances per lane and
+// round (four 16-byte loads in flight per array) in a compact loop: fully unrolled code, run once, was bound by
+// instruction fetch (39 us against 19 us for batch 4096).
+namespace {
+__device__ __forceinline__ int order_key(float e) {
+  const int key = (int)(e * 0.04f);
+  return key < 0 ? 0 : (key > 160 ? 160 : key);
+}
+__device__ __forceinline__ float order_ema(float e0, float it) { return (e0 == 0.0f) ? it : e0 + (it - e0) * 0.125f; }
+}  // namespace
+
+__global__ __launch_bounds__(64) void mpc_order_kernel(const int* __restrict__ iters, float* __restrict__ ema,
+                                                       int* __restrict__ order, int B) {
   // key = exponential moving average (1/8) of the instance's iteration counts: a better predictor of the next solve
   // than the last count alone (simulated makespan, scripts/gpu_lpt_sim.py: 1.12x instead of 1.17x of the lower bound)
+  constexpr int U = 4, R = 64 * 4 * U;  // instances per round
   __shared__ int hist[162];
   __shared__ int offs[162];
-  for (int i = threadIdx.x; i < 162; i += blockDim.x) hist[i] = 0;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 162; i += 64) hist[i] = 0;
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const float it = (float)iters[b], e0 = ema[b];
-    const float e = (e0 == 0.0f) ? it : e0 + (it - e0) * 0.125f;
+  const int Bv = B - B % R;  // whole rounds, vector loads (hipMalloc'd arrays: 16-byte aligned); the rest one by one
+  for (int base = 0; base < Bv; base += R) {
+    int4 it[U];
+    float4 e[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int b = base + (u * 64 + lane) * 4;
+      it[u] = *reinterpret_cast<const int4*>(iters + b);
+      e[u] = *reinterpret_cast<const float4*>(ema + b);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int b = base + (u * 64 + lane) * 4;
+      e[u].x = order_ema(e[u].x, (float)it[u].x);
+      e[u].y = order_ema(e[u].y, (float)it[u].y);
+      e[u].z = order_ema(e[u].z, (float)it[u].z);
+      e[u].w = order_ema(e[u].w, (float)it[u].w);
+      *reinterpret_cast<float4*>(ema + b) = e[u];
+      atomicAdd(&hist[order_key(e[u].x)], 1);
+      atomicAdd(&hist[order_key(e[u].y)], 1);
+      atomicAdd(&hist[order_key(e[u].z)], 1);
+      atomicAdd(&hist[order_key(e[u].w)], 1);
+    }
+  }
+  for (int b = Bv + lane; b < B; b += 64) {
+    const float e = order_ema(ema[b], (float)iters[b]);
     ema[b] = e;
-    int key = (int)(e * 0.04f);
-    key = key < 0 ? 0 : (key > 160 ? 160 : key);
-    atomicAdd(&hist[key], 1);
+    atomicAdd(&hist[order_key(e)], 1);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int kk = 160; kk >= 0; kk--) { offs[kk] = run; run += hist[kk]; }
+  // exclusive suffix sums over the 161 keys (largest key first): three keys per lane, wave scan of the lane totals
+  {
+    const int k0 = 160 - 3 * lane;  // this lane's keys k0, k0-1, k0-2 (lanes 0..53 cover 160..-1)
+    int h[3], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { h[j] = (k0 - j >= 0) ? hist[k0 - j] : 0; tot += h[j]; }
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    int run = incl - tot;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { if (k0 - j >= 0) offs[k0 - j] = run; run += h[j]; }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    int key = (int)(ema[b] * 0.04f);
-    key = key < 0 ? 0 : (key > 160 ? 160 : key);
-    order[atomicAdd(&offs[key], 1)] = b;
+  for (int base = 0; base < Bv; base += R) {
+    float4 e[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) e[u] = *reinterpret_cast<const float4*>(ema + base + (u * 64 + lane) * 4);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int b = base + (u * 64 + lane) * 4;
+      order[atomicAdd(&offs[order_key(e[u].x)], 1)] = b;
+      order[atomicAdd(&offs[order_key(e[u].y)], 1)] = b + 1;
+      order[atomicAdd(&offs[order_key(e[u].z)], 1)] = b + 2;
+      order[atomicAdd(&offs[order_key(e[u].w)], 1)] = b + 3;
+    }
   }
+  for (int b = Bv + lane; b < B; b += 64) order[atomicAdd(&offs[order_key(ema[b])], 1)] = b;
 }
 
 int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, iters, ema, order, B);
+  hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(64), 0, stream, iters, ema, order, B);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -406,6 +406,17 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   return 0;
 }
 
+extern "C" int qrw_mpc_get_order(qrw_handle h, int32_t* h_order, float* h_ema, int32_t* has_order) {
+  if (!h || !has_order) return fail(-1, "qrw_mpc_get_order: null argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_order sync");
+  *has_order = h->mpc_have_order ? 1 : 0;
+  const size_t B = h->cfg.batch;
+  if (h_order) HIP_OK(hipMemcpy(h_order, h->mpc_order, B * sizeof(int32_t), hipMemcpyDeviceToHost), "qrw_mpc_get_order");
+  if (h_ema) HIP_OK(hipMemcpy(h_ema, h->mpc_ema, B * sizeof(float), hipMemcpyDeviceToHost), "qrw_mpc_get_order ema");
+  return 0;
+}
+
 extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h_z, double* h_y, double* h_D,
                                  double* h_E, double* h_c) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_state: bad argument");

@@ -51,6 +51,7 @@ SIGNATURES = {
     "qrw_mpc_sequence_error": (C.c_int, [_vp, _ip]),
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "qrw_mpc_get_order": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
     "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),
     "qrw_wbc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
@@ -522,6 +523,13 @@ class Batch:
         _check(self._lib.qrw_mpc_get_stats(self._handle, it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _p(rho),
                                            _p(pri), _p(dua)), "qrw_mpc_get_stats")
         return dict(iters=it, status=st, rho=rho, pri_res=pri, dua_res=dua)
+
+    def mpc_order(self):
+        """Diagnostic: (order, ema) of the next solve's longest-first block order, or None while there is none."""
+        order, ema, has = np.empty(self.B, np.int32), np.empty(self.B, np.float32), C.c_int32(0)
+        _check(self._lib.qrw_mpc_get_order(self._handle, order.ctypes.data_as(C.c_void_p), ema.ctypes.data_as(C.c_void_p),
+                                           C.cast(C.byref(has), C.c_void_p)), "qrw_mpc_get_order")
+        return (order, ema) if has.value else None
 
     def mpc_state(self, b=0):
         N = self.N

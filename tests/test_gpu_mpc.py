@@ -199,6 +199,34 @@ def test_full_size_batch_properties(synth_mod):
     assert np.array_equal(o2, out[idx])
 
 
+@pytest.mark.parametrize("B", [1025, 4096, 5000])
+def test_block_order_is_a_permutation_sorted_by_the_moving_average(synth_mod, B):
+    """The longest-first block order the next launch uses (mpc_order_kernel, one wavefront): a permutation of 0..B-1
+    whose keys (moving average of the iteration counts, in bins of 25) never increase; none for batches <= 1024.
+    An order entry out of range would send a workgroup to another instance's memory, so this is checked directly."""
+    import qrw_hip
+
+    N = 16
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=20261100)
+    eng = qrw_hip.Batch(B, N)
+    assert eng.mpc_order() is None
+    ema_ref = np.zeros(B, np.float32)
+    for s in range(3):
+        d = sb.step(s)
+        eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        it = eng.mpc_stats()["iters"].astype(np.float32)
+        ema_ref = np.where(ema_ref == 0, it, ema_ref + (it - ema_ref) * np.float32(0.125)).astype(np.float32)
+        order, ema = eng.mpc_order()
+        assert np.array_equal(np.sort(order), np.arange(B, dtype=np.int32))
+        assert np.allclose(ema, ema_ref, rtol=1e-6)
+        key = np.clip((ema * np.float32(0.04)).astype(np.int32), 0, 160)
+        assert (np.diff(key[order]) <= 0).all()
+    small = qrw_hip.Batch(64, N)
+    d = synth_mod.SyntheticBatch(64, N).step(0)
+    small.mpc_solve_host(d["xref"], d["fsteps"], 0)
+    assert small.mpc_order() is None
+
+
 def test_nan_input_poisons_one_instance_only(oracle_mod, synth_mod):
     """A NaN in one instance's reference trajectory: OSQP's residual tests all compare false, the solve runs to
     max_iter and keeps its NaN iterate (store_solution only cold-starts on infeasible / non-convex statuses); the
