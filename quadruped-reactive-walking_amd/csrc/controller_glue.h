@@ -31,23 +31,38 @@ __device__ __forceinline__ void cross3(const double a[3], const double b[3], dou
 }
 
 // Controller.updateState (scripts/Controller.py:381-426): in0 joystick v_ref [6], in1 q_filt [19], in2 v_filt [18], in3 RPY [3]
+// Every operand is read before the first store: the compiler must keep a load behind any earlier store that might alias it,
+// and with one thread per instance each such load is a full HBM round trip on the critical path.
 __device__ __forceinline__ void update_state(const ControllerArgs& a, int b) {
   const CS s = state_of(a, b);
   const double dt = a.dt_wbc;
-  const double* jv = a.in0 + (size_t)b * 6;
-  const double* qf = a.in1 + (size_t)b * 19;
-  const double* vf = a.in2 + (size_t)b * 18;
-  const double* rpy = a.in3 + (size_t)b * 3;
+  double jv[6], qf[13], vf[18], rpy[3];  // qf: element 2 and the joints 7..18
+  {
+    const double* pj = a.in0 + (size_t)b * 6;
+    const double* pq = a.in1 + (size_t)b * 19;
+    const double* pv = a.in2 + (size_t)b * 18;
+    const double* pr = a.in3 + (size_t)b * 3;
+#pragma unroll
+    for (int i = 0; i < 6; i++) jv[i] = pj[i];
+    qf[0] = pq[2];
+#pragma unroll
+    for (int i = 0; i < 12; i++) qf[1 + i] = pq[7 + i];
+#pragma unroll
+    for (int i = 0; i < 18; i++) vf[i] = pv[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) rpy[i] = pr[i];
+  }
+  const double yaw0 = s(cYAW), qx0 = s(cQX), qy0 = s(cQY);
+#pragma unroll
   for (int i = 0; i < 6; i++) s(cVREF + i) = jv[i];
-  const double yaw0 = s(cYAW);
   const double c0 = cos(yaw0), s0 = sin(yaw0);
-  const double qx = s(cQX) + (c0 * jv[0] + -s0 * jv[1]) * dt;
-  const double qy = s(cQY) + (s0 * jv[0] + c0 * jv[1]) * dt;
+  const double qx = qx0 + (c0 * jv[0] + -s0 * jv[1]) * dt;
+  const double qy = qy0 + (s0 * jv[0] + c0 * jv[1]) * dt;
   s(cQX) = qx; s(cQY) = qy;
   const double yaw = yaw0 + jv[5] * dt;
   s(cYAW) = yaw;
   double* q = a.out0 + (size_t)b * 19;
-  q[0] = qx; q[1] = qy; q[2] = qf[2];
+  q[0] = qx; q[1] = qy; q[2] = qf[0];
   {  // EulerToQuaternion(roll, pitch, yaw_estim) (scripts/Estimator.py:672-684)
     const double sr = sin(rpy[0] / 2.), cr = cos(rpy[0] / 2.), sp = sin(rpy[1] / 2.), cp = cos(rpy[1] / 2.),
                  sy = sin(yaw / 2.), cy = cos(yaw / 2.);
@@ -56,19 +71,25 @@ __device__ __forceinline__ void update_state(const ControllerArgs& a, int b) {
     q[5] = cr * cp * sy - sr * sp * cy;
     q[6] = cr * cp * cy + sr * sp * sy;
   }
-  for (int i = 7; i < 19; i++) q[i] = qf[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) q[7 + i] = qf[1 + i];
   double* v = a.out1 + (size_t)b * 18;
+#pragma unroll
   for (int i = 0; i < 18; i++) v[i] = vf[i];
   {  // hRb = EulerToRotation(roll, pitch, 0) = Ry(pitch) Rx(roll) (scripts/utils_mpc.py:87-107)
     const double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]);
     const double R[9] = {cp, sp * sr, sp * cr, 0.0, cr, -sr, -sp, cp * sr, cp * cr};
     double* hv = a.out2 + (size_t)b * 6;
+#pragma unroll
     for (int r = 0; r < 3; r++) {
       hv[r] = R[r * 3] * vf[0] + R[r * 3 + 1] * vf[1] + R[r * 3 + 2] * vf[2];
       hv[3 + r] = R[r * 3] * vf[3] + R[r * 3 + 1] * vf[4] + R[r * 3 + 2] * vf[5];
     }
   }
-  if (a.out3) for (int i = 0; i < 6; i++) a.out3[(size_t)b * 6 + i] = jv[i];
+  if (a.out3) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.out3[(size_t)b * 6 + i] = jv[i];
+  }
   if (a.out4) {  // oRh (9) | oTh (3)
     const double c = cos(yaw), sn = sin(yaw);
     double* o = a.out4 + (size_t)b * 12;
@@ -78,6 +99,7 @@ __device__ __forceinline__ void update_state(const ControllerArgs& a, int b) {
 }
 
 // WBC target assembly (scripts/Controller.py:258-296): in0 x_f_mpc [24][N], in1 xref [12][N+1], in2 feet pva [3][3][4], in3 v [18]
+// Operands are read in two batches ahead of the stores (see update_state).
 __device__ __forceinline__ void wbc_inputs(const ControllerArgs& a, int b) {
   const CS s = state_of(a, b);
   const double dt = a.dt_wbc, h_ref = a.h_ref;
@@ -85,37 +107,59 @@ __device__ __forceinline__ void wbc_inputs(const ControllerArgs& a, int b) {
   const double* xf = a.in0 + (size_t)b * 24 * N;
   const double* xr = a.in1 + (size_t)b * 12 * (N + 1);
   const double* pva = a.in2 + (size_t)b * 36;
-  const double* vin = a.in3 + (size_t)b * 18;
+  double xf0[24], xr1[6], qdes[12], vref[6], vdes[12];
+#pragma unroll
+  for (int i = 0; i < 24; i++) xf0[i] = xf[i * N];                       // column 0 of the MPC result
+#pragma unroll
+  for (int i = 0; i < 6; i++) xr1[i] = xr[(6 + i) * (N + 1) + 1];       // rows 6..11, column 1 of xref
+#pragma unroll
+  for (int i = 0; i < 12; i++) { qdes[i] = s(cQDES + i); vdes[i] = s(cVDES + i); }
+#pragma unroll
+  for (int i = 0; i < 6; i++) vref[i] = s(cVREF + i);
+  const double yaw = s(cYAW), qx = s(cQX), qy = s(cQY);
+  double pcmd[12], vcmd[12], pv_[36];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { pcmd[i] = s(cPCMD + i); vcmd[i] = s(cVCMD + i); }
+#pragma unroll
+  for (int i = 0; i < 36; i++) pv_[i] = pva[i];
+
   double* xw = a.out0 ? a.out0 + (size_t)b * 24 : nullptr;
   if (xw) {
-    for (int i = 0; i < 24; i++) xw[i] = xf[i * N];
-    xw[0] = dt * xr[6 * (N + 1) + 1];
-    xw[1] = dt * xr[7 * (N + 1) + 1];
+    xw[0] = dt * xr1[0];
+    xw[1] = dt * xr1[1];
     xw[2] = h_ref; xw[3] = 0.0; xw[4] = 0.0;
-    xw[5] = dt * xr[11 * (N + 1) + 1];
-    for (int i = 6; i < 12; i++) xw[i] = xr[i * (N + 1) + 1];
+    xw[5] = dt * xr1[5];
+#pragma unroll
+    for (int i = 6; i < 12; i++) xw[i] = xr1[i - 6];
+#pragma unroll
+    for (int i = 12; i < 24; i++) xw[i] = xf0[i];
   }
   double* qw = a.out1 + (size_t)b * 19;
-  for (int i = 0; i < 7; i++) qw[i] = 0.0;
-  qw[2] = h_ref; qw[6] = 1.0;
-  for (int i = 0; i < 12; i++) qw[7 + i] = s(cQDES + i);
+#pragma unroll
+  for (int i = 0; i < 7; i++) qw[i] = (i == 2) ? h_ref : (i == 6) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) qw[7 + i] = qdes[i];
   double* bv = a.out2 + (size_t)b * 18;
-  for (int i = 0; i < 6; i++) bv[i] = s(cVREF + i);
-  for (int i = 0; i < 12; i++) bv[6 + i] = s(cVDES + i);
-  (void)vin;
-  if (a.out3) for (int i = 0; i < 12; i++) a.out3[(size_t)b * 12 + i] = xf[(12 + i) * N];
-  const double yaw = s(cYAW);
+#pragma unroll
+  for (int i = 0; i < 6; i++) bv[i] = vref[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) bv[6 + i] = vdes[i];
+  if (a.out3) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) a.out3[(size_t)b * 12 + i] = xf0[12 + i];
+  }
   const double c = cos(yaw), sn = sin(yaw);
-  const double w[3] = {s(cVREF + 3), s(cVREF + 4), s(cVREF + 5)};
-  const double vl[3] = {s(cVREF + 0), s(cVREF + 1), s(cVREF + 2)};
+  const double w[3] = {vref[3], vref[4], vref[5]};
+  const double vl[3] = {vref[0], vref[1], vref[2]};
   double* fc = a.out4 + (size_t)b * 12;  // planes p | v | a, each [B][3][4]
   const size_t pl = (size_t)a.B * 12;
+#pragma unroll
   for (int f = 0; f < 4; f++) {
-    const double pp[3] = {s(cPCMD + f), s(cPCMD + 4 + f), s(cPCMD + 8 + f)};
-    const double pv[3] = {s(cVCMD + f), s(cVCMD + 4 + f), s(cVCMD + 8 + f)};
-    const double pos[3] = {pva[0 * 4 + f], pva[1 * 4 + f], pva[2 * 4 + f]};
-    const double vel[3] = {pva[12 + 0 * 4 + f], pva[12 + 1 * 4 + f], pva[12 + 2 * 4 + f]};
-    const double acc[3] = {pva[24 + 0 * 4 + f], pva[24 + 1 * 4 + f], pva[24 + 2 * 4 + f]};
+    const double pp[3] = {pcmd[f], pcmd[4 + f], pcmd[8 + f]};
+    const double pv[3] = {vcmd[f], vcmd[4 + f], vcmd[8 + f]};
+    const double pos[3] = {pv_[0 * 4 + f], pv_[1 * 4 + f], pv_[2 * 4 + f]};
+    const double vel[3] = {pv_[12 + 0 * 4 + f], pv_[12 + 1 * 4 + f], pv_[12 + 2 * 4 + f]};
+    const double acc[3] = {pv_[24 + 0 * 4 + f], pv_[24 + 1 * 4 + f], pv_[24 + 2 * 4 + f]};
     double wxp[3], wxwxp[3], wxv[3];
     cross3(w, pp, wxp);
     cross3(w, wxp, wxwxp);
@@ -123,8 +167,9 @@ __device__ __forceinline__ void wbc_inputs(const ControllerArgs& a, int b) {
     // oRh' = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
     const double ra[3] = {c * acc[0] + sn * acc[1], -sn * acc[0] + c * acc[1], acc[2]};
     const double rv[3] = {c * vel[0] + sn * vel[1], -sn * vel[0] + c * vel[1], vel[2]};
-    const double dp[3] = {pos[0] - 0.0 - s(cQX), pos[1] - 0.0 - s(cQY), pos[2] - h_ref - 0.0};
+    const double dp[3] = {pos[0] - 0.0 - qx, pos[1] - 0.0 - qy, pos[2] - h_ref - 0.0};
     const double rp[3] = {c * dp[0] + sn * dp[1], -sn * dp[0] + c * dp[1], dp[2]};
+#pragma unroll
     for (int r = 0; r < 3; r++) {
       const double an = ra[r] - wxwxp[r] - 2 * wxv[r];
       const double vn = (rv[r] - vl[r]) - wxp[r];

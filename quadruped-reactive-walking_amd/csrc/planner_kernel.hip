@@ -21,6 +21,15 @@
 
 namespace qrw {
 
+// -DQRW_PROFILE_PRE (diagnostic build, scripts/gpu_loop_only.py): clocks per phase of control_pre_kernel, summed over its
+// wavefronts and printed to stderr every 50th launch (the figures quoted in DESIGN.md 4.4)
+#ifdef QRW_PROFILE_PRE
+__device__ unsigned long long qrw_pre_prof[16];
+#define PP(k_) do { if (threadIdx.x == 0 && pp_last != 0) { const long long t__ = clock64(); atomicAdd(&qrw_pre_prof[k_], (unsigned long long)(t__ - pp_last)); pp_last = t__; } } while (0)
+#else
+#define PP(k_) do { } while (0)
+#endif
+
 namespace {
 
 struct PS {  // accessor of one instance's planner state (item-major)
@@ -204,21 +213,22 @@ __device__ void quat_to_rpy(const double* q, double rpy[3]) {
 }
 
 // StatePlanner::computeReferenceStates (src/StatePlanner.cpp:21-61): writes xref[12][N+1] of this instance
-__device__ void state_compute(const PlannerArgs& a, const double* q7, const double* v6, const double* vref6,
+__device__ void state_compute(const PlannerArgs& a, const double* q7, const double* rpy, const double* v6, const double* vref6,
                               double z_average, double* X) {
   const int n = a.n_steps, ld = n + 1;
-  double rpy[3];
-  quat_to_rpy(q7 + 3, rpy);
   X[0 * ld] = 0.0; X[1 * ld] = 0.0; X[2 * ld] = q7[2];
   X[3 * ld] = rpy[0]; X[4 * ld] = rpy[1]; X[5 * ld] = 0.0;
   for (int i = 0; i < 3; i++) { X[(6 + i) * ld] = v6[i]; X[(9 + i) * ld] = v6[3 + i]; }
   const double T_mpc = a.T_mpc;
   for (int i = 0; i < n; i++) {
     const double dtv = (n == 1 || i == n - 1) ? T_mpc : a.dt_mpc + i * ((T_mpc - a.dt_mpc) / (n - 1));  // LinSpaced
+    // one sine and one cosine per step: the reference evaluates sin / cos of this same product three times each (:39-56)
+    const double yaw = vref6[5] * dtv;
+    const double sy = sin(yaw), cy = cos(yaw);
     double x, y;
     if (vref6[5] != 0) {
-      x = (vref6[0] * sin(vref6[5] * dtv) + vref6[1] * (cos(vref6[5] * dtv) - 1.0)) / vref6[5];
-      y = (vref6[1] * sin(vref6[5] * dtv) - vref6[0] * (cos(vref6[5] * dtv) - 1.0)) / vref6[5];
+      x = (vref6[0] * sy + vref6[1] * (cy - 1.0)) / vref6[5];
+      y = (vref6[1] * sy - vref6[0] * (cy - 1.0)) / vref6[5];
     } else {
       x = vref6[0] * dtv;
       y = vref6[1] * dtv;
@@ -228,10 +238,9 @@ __device__ void state_compute(const PlannerArgs& a, const double* q7, const doub
     X[2 * ld + 1 + i] = a.h_ref + z_average;
     X[3 * ld + 1 + i] = 0.0;
     X[4 * ld + 1 + i] = 0.0;
-    const double yaw = vref6[5] * dtv;
     X[5 * ld + 1 + i] = yaw;
-    X[6 * ld + 1 + i] = vref6[0] * cos(yaw) - vref6[1] * sin(yaw);
-    X[7 * ld + 1 + i] = vref6[0] * sin(yaw) + vref6[1] * cos(yaw);
+    X[6 * ld + 1 + i] = vref6[0] * cy - vref6[1] * sy;
+    X[7 * ld + 1 + i] = vref6[0] * sy + vref6[1] * cy;
     X[8 * ld + 1 + i] = 0.0; X[9 * ld + 1 + i] = 0.0; X[10 * ld + 1 + i] = 0.0;
     X[11 * ld + 1 + i] = vref6[5];
   }
@@ -337,7 +346,7 @@ __device__ void traj_store(const FootTraj& f, const PS& s, const Lay& L) {
 }  // namespace
 
 // One thread per instance; see the note above on the register representation.
-__device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
+__device__ __forceinline__ void planner_body(const PlannerArgs& a, int b, long long& pp_last) {
   const Lay L = make_layout(a.N_gait);
   const int Ng = a.N_gait;
   PS s;
@@ -367,6 +376,21 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
     remain = s(L.remain);
   }
   bool gait_dirty = init, remain_dirty = false;
+  // Operands of the later phases are read here, ahead of the first store: a load the compiler has to keep behind a
+  // possibly aliasing store is one more HBM round trip on this single thread's critical path.
+  double cf[3][4], fs1[3][4], otgt_z[4];
+  if (a.mode & kPlanFootsteps) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { cf[r][j] = s(L.cf + r * 4 + j); fs1[r][j] = s(FSI(1, r, j)); }
+#pragma unroll
+    for (int f = 0; f < 4; f++) otgt_z[f] = s(L.otgt + 8 + f);
+  }
+  FootTraj ft;
+  double nfeet_s = 0.0, feet_s[4] = {0.0, 0.0, 0.0, 0.0};
+  bool traj_loaded = false;
+  PP(2);
 
   double q7[7] = {0, 0, 0, 0, 0, 0, 1}, hv[6] = {0, 0, 0, 0, 0, 0}, vr[6] = {0, 0, 0, 0, 0, 0};
   if (a.q7) for (int i = 0; i < 7; i++) q7[i] = a.q7[(size_t)b * a.q_ld + i];
@@ -374,6 +398,8 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
   if (a.vref) for (int i = 0; i < 6; i++) vr[i] = a.vref[(size_t)b * 6 + i];
   const int code = a.code ? a.code[b] : a.code_scalar;
   const int k = a.k;
+  double rpy[3] = {0.0, 0.0, 0.0};  // of the base quaternion: the footstep targets and the reference state both use it
+  if ((a.mode & kPlanFootsteps) || ((a.mode & kPlanState) && a.xref)) quat_to_rpy(q7 + 3, rpy);
 
   // ---- Gait::updateGait
   if (a.mode & kPlanGait) {
@@ -385,6 +411,7 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
     gait_dirty = true;
   }
 
+  PP(3);
   // ---- FootstepPlanner::updateFootsteps (src/FootstepPlanner.cpp:51-74) with computeTargetFootstep (:204-221),
   // computeFootsteps (:76-156), computeNextFootstep (:158-186), updateTargetFootsteps (:188-202), updateNewContact (:223-232)
   double otgt[12];
@@ -392,17 +419,12 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
   if (a.mode & kPlanFootsteps) {
     const double* b_v = hv;
     const double* b_vref = vr;
-    double cf[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) cf[r][j] = s(L.cf + r * 4 + j);
     if (a.refresh != 0 && newphase != 0.0) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
         if (gbit(cur, 0, j)) {
 #pragma unroll
-          for (int r = 0; r < 3; r++) cf[r][j] = s(FSI(1, r, j));
+          for (int r = 0; r < 3; r++) cf[r][j] = fs1[r][j];
         }
     }
     {
@@ -421,6 +443,7 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int j = 0; j < 4; j++) s(L.cf + r * 4 + j) = cf[r][j];
+    PP(4);
     // the table, row by row: `row` is row i-1 while row i is being built
     double row[3][4], tg[2][4];
     bool found[4] = {false, false, false, false};
@@ -444,14 +467,21 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
           for (int r = 0; r < 3; r++) nrow[r][j] = (live && gp && gc) ? row[r][j] : 0.0;
         }
         if (live) {
+          // rows in which a foot lands: one sine / cosine of the previous row's yaw for all of its feet (the reference
+          // evaluates them of this same product for dx / dy and again per landing foot, src/FootstepPlanner.cpp:101-150)
+          bool lands = false;
+#pragma unroll
+          for (int j = 0; j < 4; j++) lands = lands || (!gbit(cur, i - 1, j) && gbit(cur, i, j));
+          double c = 1.0, sn = 0.0;
+          if (lands) { const double yawp = w * dtc_prev; c = cos(yawp); sn = sin(yawp); }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const bool gp = gbit(cur, i - 1, j), gc = gbit(cur, i, j);
             if (!gp && gc) {
               double dxp, dyp;
               if (w != 0) {
-                dxp = (b_v[0] * sin(w * dtc_prev) + b_v[1] * (cos(w * dtc_prev) - 1.0)) / w;
-                dyp = (b_v[1] * sin(w * dtc_prev) - b_v[0] * (cos(w * dtc_prev) - 1.0)) / w;
+                dxp = (b_v[0] * sn + b_v[1] * (c - 1.0)) / w;
+                dyp = (b_v[1] * sn - b_v[0] * (c - 1.0)) / w;
               } else {
                 dxp = b_v[0] * dtc_prev;
                 dyp = b_v[1] * dtc_prev;
@@ -472,8 +502,6 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
               nf[0] += a.shoulders[0 * 4 + j];
               nf[1] += a.shoulders[1 * 4 + j];
               nf[2] = 0.0;
-              const double yawp = w * dtc_prev;
-              const double c = cos(yawp), sn = sin(yawp);
               nrow[0][j] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
               nrow[1][j] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
               nrow[2][j] = (0.0 * nf[0] + 0.0 * nf[1] + 1.0 * nf[2]) + 0.0;
@@ -500,8 +528,14 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
         }
       }
     }
-    double rpy[3];
-    quat_to_rpy(q7 + 3, rpy);
+    if (a.mode & kPlanTraj) {  // the foot-trajectory state: requested here so that it arrives during the target arithmetic
+      traj_load(ft, s, L);
+      nfeet_s = s(L.nfeet);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) feet_s[jj] = s(L.feet + jj);
+      traj_loaded = true;
+    }
+    PP(5);
     const double c = cos(rpy[2]), sn = sin(rpy[2]);
 #pragma unroll
     for (int f = 0; f < 4; f++) {
@@ -514,7 +548,7 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
       s(L.otgt + 4 + f) = otgt[4 + f];
     }
 #pragma unroll
-    for (int f = 0; f < 4; f++) otgt[8 + f] = s(L.otgt + 8 + f);
+    for (int f = 0; f < 4; f++) otgt[8 + f] = otgt_z[f];
     have_otgt = true;
   } else if (a.fsteps && (a.mode & kPlanOutputs)) {
     double* o = a.fsteps + (size_t)b * Ng * 12;
@@ -523,13 +557,19 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
         for (int r = 0; r < 3; r++) o[i * 12 + 3 * j + r] = s(FSI(i, r, j));
   }
 
+  PP(6);
   // ---- FootTrajectoryGenerator::update (src/FootTrajectoryGenerator.cpp:108-151)
   if (a.mode & kPlanTraj) {
     double tgt[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) tgt[e] = a.target_in ? a.target_in[(size_t)b * 12 + e] : (have_otgt ? otgt[e] : s(L.otgt + e));
-    FootTraj f;
-    traj_load(f, s, L);
+    FootTraj& f = ft;
+    if (!traj_loaded) {
+      traj_load(f, s, L);
+      nfeet_s = s(L.nfeet);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) feet_s[jj] = s(L.feet + jj);
+    }
     unsigned swing = 0;
     bool run = true;
     if ((k % a.k_mpc) == 0) {
@@ -549,9 +589,11 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
           f.t0s[i] = fmax(0.0, value);
         }
     } else {
-      const int nf = (int)s(L.nfeet);
+      const int nf = (int)nfeet_s;
       run = nf != 0;
-      for (int jj = 0; jj < nf; jj++) swing |= 1u << (int)s(L.feet + jj);
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        if (jj < nf) swing |= 1u << (int)feet_s[jj];
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (swing & (1u << i)) f.t0s[i] = fmax(0.0, f.t0s[i] + a.dt_wbc);
@@ -580,8 +622,10 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
       a.feet_pva[(size_t)b * 36 + 24 + e] = s(L.acc + e);
     }
   }
-  if ((a.mode & kPlanState) && a.xref) state_compute(a, q7, hv, vr, a.z_average, a.xref + (size_t)b * 12 * (a.n_steps + 1));
+  PP(7);
+  if ((a.mode & kPlanState) && a.xref) state_compute(a, q7, rpy, hv, vr, a.z_average, a.xref + (size_t)b * 12 * (a.n_steps + 1));
 
+  PP(8);
   // ---- remaining outputs / state
   if (a.gait && (a.mode & (kPlanGait | kPlanOutputs))) {
     double* o = a.gait + (size_t)b * Ng * 4;
@@ -600,13 +644,15 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b) {
     gm_store(s, L.des, des);
   }
   if (remain_dirty) s(L.remain) = remain;
+  PP(9);
 }
 #undef FSI
 
 __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
-  planner_body(a, b);
+  long long pp_last = 0;  // phase accounting is for control_pre_kernel only
+  planner_body(a, b, pp_last);
 }
 
 // Fused head of a control iteration (scripts/Controller.py:218-296): Controller.updateState, the four planners and --
@@ -615,10 +661,30 @@ __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
 __global__ __launch_bounds__(64) void control_pre_kernel(ControllerArgs cu, PlannerArgs p, ControllerArgs cw, int with_wbc_inputs) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= p.B) return;
+#ifdef QRW_PROFILE_PRE
+  long long pp_last = clock64();
+  if (threadIdx.x == 0) atomicAdd(&qrw_pre_prof[0], 1ull);
+#else
+  long long pp_last = 0;
+#endif
   glue::update_state(cu, b);
-  planner_body(p, b);
+  PP(1);
+  planner_body(p, b, pp_last);
   if (with_wbc_inputs) glue::wbc_inputs(cw, b);
+  PP(10);
 }
+
+#ifdef QRW_PROFILE_PRE
+static void pre_prof_dump() {  // diagnostic build only: synchronises the device
+  unsigned long long h[16];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(qrw_pre_prof), sizeof(h)) != hipSuccess || h[0] == 0) return;
+  const char* nm[11] = {"", "update_state", "planner loads", "gait update", "footsteps head", "footsteps table", "targets",
+                        "foot trajectory", "state_compute(xref)", "outputs + state stores", "wbc_inputs"};
+  fprintf(stderr, "control_pre phases (clk per wavefront, %llu wavefronts):", h[0]);
+  for (int k = 1; k <= 10; k++) fprintf(stderr, "  %s %.0f", nm[k], (double)h[k] / (double)h[0]);
+  fprintf(stderr, "\n");
+}
+#endif
 
 int planner_state_items(int N_gait) { return make_layout(N_gait).total; }
 
@@ -649,6 +715,10 @@ int planner_item_offset(int N_gait, int which) {
 
 int control_pre_launch(const ControllerArgs& cu, const PlannerArgs& p, const ControllerArgs& cw, int with_wbc_inputs,
                        hipStream_t stream) {
+#ifdef QRW_PROFILE_PRE
+  static int calls = 0;
+  if (++calls % 50 == 0) pre_prof_dump();
+#endif
   hipLaunchKernelGGL(control_pre_kernel, dim3((p.B + 63) / 64), dim3(64), 0, stream, cu, p, cw, with_wbc_inputs);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
