@@ -247,20 +247,21 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
   const double sigma = 1e-6, alpha = 1.6;
   const double eps_abs = (double)(float)1e-5, eps_rel = (double)(float)1e-5;  // QPWBC.cpp:239-240
   const double eps_prim_inf = 1e-4, eps_dual_inf = 1e-4;
-  const bool first = !valid || !(st[kWsInit] != 0.0);  // padding quads always cold-start
-  double x[3], z[5], y[5], rho, gprev[3];
+  // the warm-start state is read unconditionally, together with the flag that says whether it counts: one round trip
+  // to HBM instead of two (padding quads read instance 0's)
+  const double init_flag = st[kWsInit];
+  double x[3], z[5], y[5], rho = st[kWsRho], gprev[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) { x[t] = st[kWsX + 3 * j + t]; gprev[t] = st[kWsG + 3 * j + t]; }
+#pragma unroll
+  for (int c = 0; c < 5; c++) { z[c] = st[kWsZ + 5 * j + c]; y[c] = st[kWsY + 5 * j + c]; }
+  const bool first = !valid || !(init_flag != 0.0);  // padding quads always cold-start
   if (first) {
     rho = 0.1;
 #pragma unroll
     for (int t = 0; t < 3; t++) { x[t] = 0.0; gprev[t] = io.g[t]; }
 #pragma unroll
     for (int c = 0; c < 5; c++) z[c] = y[c] = 0.0;
-  } else {
-    rho = st[kWsRho];
-#pragma unroll
-    for (int t = 0; t < 3; t++) { x[t] = st[kWsX + 3 * j + t]; gprev[t] = st[kWsG + 3 * j + t]; }
-#pragma unroll
-    for (int c = 0; c < 5; c++) { z[c] = st[kWsZ + 5 * j + c]; y[c] = st[kWsY + 5 * j + c]; }
   }
   // ---- scale_data: on setup q is the current g; inside osqp_update_P it is still the PREVIOUS call's g
   // (osqp_update_lin_cost runs afterwards, QPWBC.cpp:258-261)
@@ -828,24 +829,61 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       o[24 + 0 * 4 + j] = vf.x; o[24 + 1 * 4 + j] = vf.y; o[24 + 2 * 4 + j] = vf.z;
     }
   }
-  const double qd_leg[3] = {q[0] + qs3.x, q[1] + qs3.y, q[2] + qs3.z};
-  const double vd_leg[3] = {dqc3.x, dqc3.y, dqc3.z};
+  // The 27 values the epilogue needs again wait in LDS while the solve runs (lane-strided, conflict-free): carried in
+  // registers they were what the compiler spilled to scratch (44 dwords per lane), and the ADMM loop wants the file.
+  __shared__ double park[27 * 64];
+  {
+    double* pk = park + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      pk[(0 + t) * 64] = fc[t]; pk[(3 + t) * 64] = dq[t]; pk[(6 + t) * 64] = ddq[t];
+      pk[(9 + t) * 64] = (t == 0) ? q[0] + qs3.x : (t == 1) ? q[1] + qs3.y : q[2] + qs3.z;   // q_des of this leg
+      pk[(12 + t) * 64] = (t == 0) ? dqc3.x : (t == 1) ? dqc3.y : dqc3.z;                      // v_des of this leg
+    }
+    pk[15 * 64] = wb.x; pk[16 * 64] = wb.y; pk[17 * 64] = wb.z;
+    pk[18 * 64] = vb.x; pk[19 * 64] = vb.y; pk[20 * 64] = vb.z;
+#pragma unroll
+    for (int i = 0; i < 6; i++) pk[(21 + i) * 64] = gamma[i];
+  }
   QpIo io;
   qp_build(Aj, gamma, fc, j, io);
   double sol[3];
   int it, stt;
+  // re-read after the solve (not carried across it): joint angles and base quaternion for the second evaluation of the
+  // leg kinematics, and the operands of the fused result / security check
   qp_solve(io, st, j, valid, sol, it, stt);
+  double q2[3], qq[4], c_err0 = 0.0, c_qf[3] = {0.0, 0.0, 0.0}, c_vs[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 3; t++) q2[t] = qv[7 + 3 * j + t];
+#pragma unroll
+  for (int t = 0; t < 4; t++) qq[t] = qv[3 + t];
+  if (a.c_cs) {  // requested now, so that they do not cost a round trip of their own behind the torque stores
+    c_err0 = a.c_cs[bb + (size_t)glue::cERR * (size_t)a.B];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { c_qf[t] = a.c_qfilt[bb * 19 + 7 + 3 * j + t]; c_vs[t] = a.c_vsecu[bb * 12 + 3 * j + t]; }
+  }
+  double fcp[3], dqp[3], ddqp[3], qd_leg[3], vd_leg[3], gammap[6];
+  V3 wbp, vbp;
+  {
+    int off = threadIdx.x;
+    asm volatile("" : "+v"(off));  // opaque address: the values are read back, not kept alive across the solve
+    const double* pk = park + off;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      fcp[t] = pk[(0 + t) * 64]; dqp[t] = pk[(3 + t) * 64]; ddqp[t] = pk[(6 + t) * 64];
+      qd_leg[t] = pk[(9 + t) * 64]; vd_leg[t] = pk[(12 + t) * 64];
+    }
+    wbp = mk(pk[15 * 64], pk[16 * 64], pk[17 * 64]);
+    vbp = mk(pk[18 * 64], pk[19 * 64], pk[20 * 64]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) gammap[i] = pk[(21 + i) * 64];
+  }
   double dd[6];
-  const double fw[3] = {sol[0] + fc[0], sol[1] + fc[1], sol[2] + fc[2]};
+  const double fw[3] = {sol[0] + fcp[0], sol[1] + fcp[1], sol[2] + fcp[2]};
   double tau2[3], tff[3];
   {
-    // recomputed (not carried across the solve): joint angles and quaternion are re-read so that the compiler cannot
-    // merge these with the first evaluation
-    double q2[3], qq[4];
-#pragma unroll
-    for (int t = 0; t < 3; t++) q2[t] = qv[7 + 3 * j + t];
-#pragma unroll
-    for (int t = 0; t < 4; t++) qq[t] = qv[3 + t];
+    // recomputed (not carried across the solve): the opaque asm keeps the compiler from merging this evaluation with
+    // the first one
     asm volatile("" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]));
     const LegKin K2 = leg_kinematics(C, q2);
     M3 Rb2;
@@ -872,13 +910,13 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
         const double Ait = (1.0 / a.Y[i]) * xv;
         acc = (t == 0) ? Ait * sol[0] : acc + Ait * sol[t];
       }
-      dd[i] = quad_sum(acc) + gamma[i];
+      dd[i] = quad_sum(acc) + gammap[i];
     }
     const V3 alb = mk(dd[3], dd[4], dd[5]);
     const V3 grav2 = mulT(Rb2, mk(0.0, 0.0, QRW_SOLO12_MODEL.gravity));
-    const V3 ab02 = grav2 + cross(wb, vb);
+    const V3 ab02 = grav2 + cross(wbp, vbp);
     const V3 ab1 = ab02 + mk(dd[0], dd[1], dd[2]);
-    leg_newton_euler(C, K2, dq, ddq, wb, alb, ab1, Fl, Ml, tau2);
+    leg_newton_euler(C, K2, dqp, ddqp, wbp, alb, ab1, Fl, Ml, tau2);
     // tau_ff = RNEA_delta - Jc[:, 6:]' f (QP_WBC.py:117): Jc joint block of a stance foot = Rb J_leg
     const V3 fbv = mulT(Rb2, mk(fw[0], fw[1], fw[2]));  // Rb' f
     tff[0] = tau2[0] - (stance ? dot(K2.J0, fbv) : 0.0);
@@ -896,15 +934,15 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       // 341-365; same arithmetic as glue::result, one leg per lane, flags combined over the quad)
       double* cs = a.c_cs + bb;
       const size_t cB = (size_t)a.B;
-      int err = (int)cs[(size_t)glue::cERR * cB];
+      int err = (int)c_err0;
       const double qd[3] = {qd_leg[0], qd_leg[1], qd_leg[2]};
       const double vd[3] = {vd_leg[0], vd_leg[1], vd_leg[2]};
       const double qsec[3] = {M_PI * 0.4, M_PI * 80 / 180, M_PI};
       double e1 = 0.0, e2 = 0.0, e3 = 0.0;
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        if (fabs(a.c_qfilt[bb * 19 + 7 + 3 * j + t]) > qsec[t]) e1 = 1.0;
-        if (fabs(a.c_vsecu[bb * 12 + 3 * j + t]) > 50) e2 = 1.0;
+        if (fabs(c_qf[t]) > qsec[t]) e1 = 1.0;
+        if (fabs(c_vs[t]) > 50) e2 = 1.0;
         if (fabs(tff[t]) > 8) e3 = 1.0;
       }
       e1 = quad_max(e1); e2 = quad_max(e2); e3 = quad_max(e3);
