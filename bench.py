@@ -353,29 +353,19 @@ def stream_groups_figure(B, N, N_gait, dev, W, K, data, S=2):
     S independent groups, each with its own handle and stream and no cross-group synchronisation inside the timed
     region: a step's launch ends with its longest solve (2 000-2 750 ADMM iterations against a mean of ~515) while most
     of the chip is already idle; with two groups in flight one group's stragglers run beside the other group's next step.
-    A deployment choice above the C ABI (two qrw handles per GPU), not a different kernel; more than two groups gain
-    nothing reliably (HIP multiplexes streams onto four hardware queues, scripts/gpu_subbatch_exp.py)."""
+    A deployment choice above the C ABI (two qrw handles per GPU: qrw_hip.StreamGroups), not a different kernel; three
+    groups give the same, four and more less (scripts/gpu_subbatch_exp.py)."""
     import torch
 
     import qrw_hip
 
     Bs = B // S
-    engs = [qrw_hip.Batch(Bs, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
-            for _ in range(S)]
-    streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    outs = [torch.empty((Bs, 24, N), dtype=torch.float64, device=dev) for _ in range(S)]
-    fcs = [torch.empty((Bs, 12), dtype=torch.float64, device=dev) for _ in range(S)]
-    wbs = [None] * S
-    sl = [slice(g * Bs, (g + 1) * Bs) for g in range(S)]
+    grp = qrw_hip.StreamGroups(B, groups=S, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002,
+                               device=dev.index or 0)
 
     def step(s):
-        for g in range(S):
-            with torch.cuda.stream(streams[g]):
-                engs[g].mpc_solve(data["xref"][s][sl[g]], data["fsteps"][s][sl[g]], s, out=outs[g])
-                fcs[g].copy_(outs[g][:, 12:, 0])
-                wbs[g] = engs[g].wbc_compute(data["q"][s][sl[g]], data["dq"][s][sl[g]], fcs[g], data["contacts"][s][sl[g]],
-                                             data["pgoals"][s][sl[g]], data["vgoals"][s][sl[g]], data["agoals"][s][sl[g]],
-                                             out=wbs[g])
+        grp.control_step(data["xref"][s], data["fsteps"][s], s, data["q"][s], data["dq"][s], data["contacts"][s],
+                         data["pgoals"][s], data["vgoals"][s], data["agoals"][s])
 
     torch.cuda.synchronize()
     for s in range(W):
@@ -386,8 +376,7 @@ def stream_groups_figure(B, N, N_gait, dev, W, K, data, S=2):
         step(W + i)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    for e in engs:
-        e.close()
+    grp.close()
     return {"value": S * Bs * K / el, "unit": "steps/s", "ms_per_step": 1e3 * el / K, "groups": S, "instances_per_group": Bs,
             "what": "the headline workload with the batch split into %d independent stream groups (own handle + stream each, "
                     "no cross-group synchronisation inside the timed region): straggling solves of one group overlap the "

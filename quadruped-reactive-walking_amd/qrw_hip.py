@@ -553,3 +553,67 @@ class Batch:
 
     def state_bytes(self):
         return int(self._lib.qrw_state_bytes(self._handle))
+
+
+class StreamGroups:
+    """One GPU's fleet as `groups` independent sub-batches, each with its own handle (`Batch`) and stream.
+
+    A launch of `mpc_solve` ends with its longest solve (2 000-2 750 ADMM iterations against a mean of ~515 on the bench
+    workload) while most of the chip is already idle; with two groups in flight the stragglers of one group run beside
+    the next step of the other (+10 % control steps/s at batch 4096, DESIGN.md 4.1 "Block scheduling").  The robots are
+    independent, so the results are the ones a single handle gives, bit for bit.
+
+    `control_step` enqueues MPC solve -> f_cmd -> WBC for every group on that group's stream and returns at once; the
+    outputs (views of `mpc_out`, `wbc_out[...]`, whole-fleet tensors) are valid after `synchronize()` or on the group's
+    stream.  Inputs must stay untouched until then.  Groups below 1025 instances run without the longest-first block
+    order (qrw_mpc_solve builds it for larger batches only); two groups are the measured optimum at batch 4096."""
+
+    def __init__(self, batch, groups=2, n_steps=16, N_gait=20, dt_mpc=0.02, T_gait=0.32, dt_wbc=0.002, device=0):
+        import torch
+
+        if groups < 1 or batch % groups:
+            raise QrwError("batch %d does not split into %d equal groups" % (batch, groups))
+        self.B, self.S, self.Bs, self.N, self.N_gait, self.device = int(batch), int(groups), int(batch) // int(groups), int(n_steps), int(N_gait), int(device)
+        dev = torch.device("cuda", self.device)
+        self.engines = [Batch(self.Bs, n_steps=n_steps, N_gait=N_gait, dt_mpc=dt_mpc, T_gait=T_gait, dt_wbc=dt_wbc, device=device)
+                        for _ in range(self.S)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.S)]
+        self._sl = [slice(g * self.Bs, (g + 1) * self.Bs) for g in range(self.S)]
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.mpc_out = torch.empty((self.B, 24, self.N), **f64)
+        self.f_cmd = torch.empty((self.B, 12), **f64)
+        self.wbc_out = dict(tau_ff=torch.empty((self.B, 12), **f64), qdes=torch.empty((self.B, 19), **f64),
+                            vdes=torch.empty((self.B, 18), **f64), f_with_delta=torch.empty((self.B, 12), **f64),
+                            ddq_res=torch.empty((self.B, 6), **f64), feet=torch.empty((self.B, 3, 3, 4), **f64))
+        self._wbc_views = [{k: v[sl] for k, v in self.wbc_out.items()} for sl in self._sl]
+
+    def control_step(self, xref, fsteps, num_iter, q, dq, contacts, pgoals, vgoals, agoals):
+        """One control step (MPC + WBC, 1:1) of the whole fleet; all inputs whole-fleet CUDA float64 tensors."""
+        import torch
+
+        cur = torch.cuda.current_stream(self.device)
+        for g, (eng, st, sl) in enumerate(zip(self.engines, self.streams, self._sl)):
+            st.wait_stream(cur)  # inputs produced on the caller's stream are ready
+            with torch.cuda.stream(st):
+                eng.mpc_solve(xref[sl], fsteps[sl], num_iter, out=self.mpc_out[sl])
+                self.f_cmd[sl].copy_(self.mpc_out[sl][:, 12:, 0])
+                eng.wbc_compute(q[sl], dq[sl], self.f_cmd[sl], contacts[sl], pgoals[sl], vgoals[sl], agoals[sl],
+                                out=self._wbc_views[g])
+        return self.wbc_out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def join(self, stream=None):
+        """Make `stream` (default: the caller's current stream) wait for every group's queued work, without blocking the host."""
+        import torch
+
+        stream = stream or torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            stream.wait_stream(st)
+
+    def close(self):
+        self.synchronize()
+        for e in self.engines:
+            e.close()

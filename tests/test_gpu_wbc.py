@@ -294,3 +294,30 @@ def test_replay_batch_equals_solve_batch_calls(synth_mod):
     assert np.array_equal(got.cpu().numpy(), np.stack(ref))
     b.get_latest_result_batch()
     assert np.array_equal(b.get_latest_result_batch().cpu().numpy(), ref[-1])
+
+
+def test_stream_groups_give_the_single_handle_results(synth_mod):
+    """qrw_hip.StreamGroups (the fleet as two sub-batches with their own handles and streams, stepping without
+    cross-group synchronisation): robots are independent, so MPC result and torques equal a single handle's bit for bit."""
+    import torch
+
+    import qrw_hip
+
+    B, N = 2052, 16  # 1026 per group: the longest-first block order is in use in both groups
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=20261200)
+    one = qrw_hip.Batch(B, N)
+    grp = qrw_hip.StreamGroups(B, groups=2, n_steps=N)
+    keys = ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")
+    for s in range(4):
+        d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sb.step(s).items() if k in keys}
+        out = one.mpc_solve(d["xref"], d["fsteps"], s)
+        ref = one.wbc_compute(d["q"], d["dq"], out[:, 12:, 0].contiguous(), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+        res = grp.control_step(d["xref"], d["fsteps"], s, d["q"], d["dq"], d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+        grp.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(grp.mpc_out, out)
+        for k in ("tau_ff", "f_with_delta", "qdes", "vdes", "ddq_res", "feet"):
+            assert torch.equal(res[k], ref[k]), (s, k)
+    grp.close()
+    with pytest.raises(qrw_hip.QrwError):
+        qrw_hip.StreamGroups(7, groups=2)
