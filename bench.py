@@ -483,7 +483,7 @@ def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
                     "%d timed calls after %d warm-up calls, inputs replayed from HBM" % (K, W)}
 
 
-def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False):
+def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=32):
     """Secondary figure: the reference's own 1:10 MPC:WBC ratio, whole Controller.compute iterations
     (scripts/Controller.py:200-326) on the device — updateState, the four planners, one MPC solve every k_mpc
     iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM.
@@ -497,7 +497,7 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     # the masked streams synchronise with the legacy default stream: keep the caller's own work off it
     with torch.cuda.stream(torch.cuda.Stream(dev)):
         ctl = Controller_batch(B, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=k_mpc, T_gait=0.02 * N, T_mpc=0.02 * N,
-                               N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing)
+                               N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing, loop_cus=loop_cus)
         # half the joystick range of the headline workload: at up to 1.5 m/s a sixth of the instances run into the
         # controller's joint-limit / torque security stop within 100 iterations (reference behaviour), which would
         # make the figure depend on how many robots have already been stopped
