@@ -84,3 +84,43 @@ def test_shipped_mpc_kernel_spills_nothing_to_scratch():
     agprs = int(re.search(r"AGPRs: (\d+)", blk).group(1))
     vspill = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
     assert scratch == 0 and vspill == 0 and agprs < 256, (scratch, vspill, agprs)
+
+
+def _build_cabi_demo(tmp_path):
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    pkg = os.path.join(ROOT, "quadruped-reactive-walking_amd")
+    if not os.path.exists(os.path.join(pkg, "libqrw_hip.so")):
+        pytest.skip("libqrw_hip.so not built")
+    exe = str(tmp_path / "cabi_demo")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "cabi_demo.c"), "-o", exe, "-L" + pkg, "-lqrw_hip", "-lm",
+                        "-Wl,-rpath," + pkg], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_header_is_plain_c_and_links_without_python(tmp_path):
+    """include/qrw_hip.h compiles as C99 with gcc and a plain C program links against libqrw_hip.so (no Python, torch or
+    HIP headers on the caller's side): examples/cabi_demo.c.  Without a GPU the library must refuse loudly (no CPU path)."""
+    import subprocess
+
+    exe = _build_cabi_demo(tmp_path)
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stderr[-500:])
+    if r.returncode == 3:
+        assert "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_gets_the_reference_known_answer(tmp_path):
+    """The reference's four-stance known answer (scripts/test_mpc.py:54-85) through the C ABI from a plain C program."""
+    import subprocess
+
+    exe = _build_cabi_demo(tmp_path)
+    r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    assert r.stdout.count(" ok") == 5 and "MISMATCH" not in r.stdout
