@@ -477,8 +477,28 @@ def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
     iters = it_dev.cpu().numpy().astype(np.float64)
     flops = iters.sum() * f_iter(N) + K * B * (f_fac(N) + F_ASM)
     eng.close()
+    # the same replay as two stream groups (qrw_hip.StreamGroups: identical results, one group's stragglers beside the
+    # other group's next step)
+    grp = qrw_hip.StreamGroups(B, groups=2, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002,
+                               device=dev.index or 0)
+
+    def gstep(s):
+        t = seq[s]
+        grp.control_step(t["xref"], t["fsteps"], s, t["q"], t["dq"], t["contacts"], t["pgoals"], t["vgoals"], t["agoals"])
+
+    for s in range(W):
+        gstep(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        gstep(W + i)
+    torch.cuda.synchronize()
+    el2 = time.perf_counter() - t0
+    same = bool(torch.equal(grp.mpc_out, mpc_out))
+    grp.close()
     return {"value": B * K / el, "unit": "steps/s", "ms_per_step": 1e3 * el / K, "mean_admm_iters": float(iters.mean()),
             "max_admm_iters": int(iters.max()), "roofline_frac": float(flops / (ms.sum() * 1e-3) / PEAK_FP64),
+            "two_stream_groups_steps_per_s": B * K / el2, "two_stream_groups_last_result_identical": same,
             "what": "SURVEY 8(d) closed receding-horizon sequence (state advanced with the MPC's own prediction), "
                     "%d timed calls after %d warm-up calls, inputs replayed from HBM" % (K, W)}
 

@@ -566,7 +566,16 @@ class StreamGroups:
     `control_step` enqueues MPC solve -> f_cmd -> WBC for every group on that group's stream and returns at once; the
     outputs (views of `mpc_out`, `wbc_out[...]`, whole-fleet tensors) are valid after `synchronize()` or on the group's
     stream.  Inputs must stay untouched until then.  Groups below 1025 instances run without the longest-first block
-    order (qrw_mpc_solve builds it for larger batches only); two groups are the measured optimum at batch 4096."""
+    order (qrw_mpc_solve builds it for larger batches only); two groups are the measured optimum at batch 4096.
+
+    The groups only overlap if their streams sit on DIFFERENT hardware queues.  HIP multiplexes a process's streams onto
+    four of them (GPU_MAX_HW_QUEUES) in the order of first use, so a process that has already used other streams can end
+    up with both groups on one queue — measured: 600 k instead of 970 k steps/s on the closed sequence with exactly two
+    streams used earlier (scripts/gpu_stream_pool_exp.py).  The streams are therefore created once per device and group
+    index and shared by every StreamGroups object of the process; keep the number of other live streams small, or raise
+    GPU_MAX_HW_QUEUES before the first HIP call."""
+
+    _streams = {}  # (device, group index) -> torch.cuda.Stream, shared by all instances
 
     def __init__(self, batch, groups=2, n_steps=16, N_gait=20, dt_mpc=0.02, T_gait=0.32, dt_wbc=0.002, device=0):
         import torch
@@ -577,7 +586,10 @@ class StreamGroups:
         dev = torch.device("cuda", self.device)
         self.engines = [Batch(self.Bs, n_steps=n_steps, N_gait=N_gait, dt_mpc=dt_mpc, T_gait=T_gait, dt_wbc=dt_wbc, device=device)
                         for _ in range(self.S)]
-        self.streams = [torch.cuda.Stream(dev) for _ in range(self.S)]
+        for g in range(self.S):
+            if (self.device, g) not in StreamGroups._streams:
+                StreamGroups._streams[(self.device, g)] = torch.cuda.Stream(dev)
+        self.streams = [StreamGroups._streams[(self.device, g)] for g in range(self.S)]
         self._sl = [slice(g * self.Bs, (g + 1) * self.Bs) for g in range(self.S)]
         f64 = dict(dtype=torch.float64, device=dev)
         self.mpc_out = torch.empty((self.B, 24, self.N), **f64)
