@@ -27,6 +27,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in the order of first use; this
+# process uses more than four over its legs, and two stream groups that land on one queue serialise (DESIGN.md 4.1:
+# 600 k instead of 970 k steps/s).  Read by the runtime at its first call: set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 

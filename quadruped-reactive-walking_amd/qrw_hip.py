@@ -90,6 +90,9 @@ def load_library():
     if not os.path.exists(_LIB_PATH):
         raise QrwError("libqrw_hip.so is not built (run `make -C quadruped-reactive-walking_amd/csrc` or "
                        "__graft_entry__.build()); there is no CPU fallback")
+    # more hardware queues than HIP's default four, for the multi-stream modes (StreamGroups, the asynchronous MPC mode):
+    # streams that share a queue serialise.  Only effective if nothing in the process has touched the GPU yet.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the host API
@@ -572,8 +575,8 @@ class StreamGroups:
     four of them (GPU_MAX_HW_QUEUES) in the order of first use, so a process that has already used other streams can end
     up with both groups on one queue — measured: 600 k instead of 970 k steps/s on the closed sequence with exactly two
     streams used earlier (scripts/gpu_stream_pool_exp.py).  The streams are therefore created once per device and group
-    index and shared by every StreamGroups object of the process; keep the number of other live streams small, or raise
-    GPU_MAX_HW_QUEUES before the first HIP call."""
+    index and shared by every StreamGroups object of the process, and load_library() raises GPU_MAX_HW_QUEUES to 8 when
+    it runs before the first HIP call of the process (set it yourself otherwise)."""
 
     _streams = {}  # (device, group index) -> torch.cuda.Stream, shared by all instances
 
