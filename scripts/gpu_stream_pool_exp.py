@@ -1,7 +1,7 @@
 """Does the number of torch pool streams USED earlier in the process change what two stream groups reach?  (bench.py measured 600 k
 for the closed sequence as two groups inside the full run and 970 k alone.)  python scripts/gpu_stream_pool_exp.py N"""
 import json, os, sys
-ROOT = "/root/repo" if not os.environ.get("GRAFT_REPO_ROOT") else os.environ["GRAFT_REPO_ROOT"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import torch
 import bench
