@@ -1,5 +1,6 @@
 """Does the number of torch pool streams USED earlier in the process change what two stream groups reach?  (bench.py measured 600 k
-for the closed sequence as two groups inside the full run and 970 k alone.)  python scripts/gpu_stream_pool_exp.py N"""
+for the closed sequence as two groups inside the full run and 970 k alone.)  GPU_MAX_HW_QUEUES=4 python scripts/gpu_stream_pool_exp.py N
+(importing bench raises the queue count to 8 unless the variable is already set: N = 2 gives 600 k with 4 queues, 955-990 k with 8 or 16)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quadruped-reactive-walking_amd")]
