@@ -238,7 +238,9 @@ int qrw_mpc_result_shift(qrw_handle h, const double *d_gait, double *d_x_f_mpc, 
  * qrw_control_pre = qrw_controller_update_state + qrw_planner_step (fed with its q, h_v, v_ref) and, when d_x_f_mpc is
  * not NULL (the MPC result to use is already known: every iteration that does not solve), + qrw_controller_wbc_inputs;
  * qrw_wbc_compute_result = qrw_wbc_compute + qrw_controller_result (scripts/Controller.py:200-326 end to end in two
- * launches plus the MPC solve every k_mpc-th iteration).  Operands as in the separate entry points. */
+ * launches plus the MPC solve every k_mpc-th iteration).  Operands as in the separate entry points.  d_fsteps and d_gait may
+ * be NULL; with d_fsteps NULL and d_x_f_mpc given (an iteration that does not solve: nobody reads the MPC's inputs) only
+ * column 0 and horizon step 1 of d_xref are written, which is all the WBC target assembly reads of it. */
 int qrw_control_pre(qrw_handle h, int32_t k, const double *d_joy_vref, const double *d_q_filt, const double *d_v_filt,
                     const double *d_rpy, const int32_t *d_code, int32_t code_scalar, const double *d_x_f_mpc, double *d_q,
                     double *d_v, double *d_hv, double *d_vref, double *d_oRh_oTh, double *d_xref, double *d_fsteps,

@@ -177,8 +177,9 @@ class Controller_batch:
             else:
                 self._not_first_iter = True
                 self.x_f_mpc = self._mpc_default
+            # nobody reads the MPC's inputs on an iteration that does not solve: fsteps / gait / most of xref are not produced
             self._pre = p = b.control_pre(k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, x_f_mpc=self.x_f_mpc,
-                                          out=self._pre)
+                                          out=self._pre, mpc_inputs=False)
         fc = p["feet_cmd"]
         self._post = w = b.wbc_compute_result(p["q_wbc"], p["b_v"], p["f_cmd"], p["contacts"], fc[0], fc[1], fc[2], q_filt,
                                               v_secu, out=self._post)

@@ -220,7 +220,8 @@ __device__ void state_compute(const PlannerArgs& a, const double* q7, const doub
   X[3 * ld] = rpy[0]; X[4 * ld] = rpy[1]; X[5 * ld] = 0.0;
   for (int i = 0; i < 3; i++) { X[(6 + i) * ld] = v6[i]; X[(9 + i) * ld] = v6[3 + i]; }
   const double T_mpc = a.T_mpc;
-  for (int i = 0; i < n; i++) {
+  const int n_out = (a.xref_steps > 0 && a.xref_steps < n) ? a.xref_steps : n;  // a caller that does not solve this iteration
+  for (int i = 0; i < n_out; i++) {
     const double dtv = (n == 1 || i == n - 1) ? T_mpc : a.dt_mpc + i * ((T_mpc - a.dt_mpc) / (n - 1));  // LinSpaced
     // one sine and one cosine per step: the reference evaluates sin / cos of this same product three times each (:39-56)
     const double yaw = vref6[5] * dtv;

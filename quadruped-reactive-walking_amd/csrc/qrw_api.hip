@@ -884,6 +884,8 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
   p.q7 = d_q; p.q_ld = 19; p.hv = d_hv; p.vref = d_vref; p.code = d_code; p.code_scalar = code_scalar;
   p.xref = d_xref; p.fsteps = d_fsteps; p.gait = d_gait; p.target = d_target; p.feet_pva = d_feet_pva;
   p.contacts = d_contacts;
+  // no fsteps wanted = this iteration does not solve: of xref only column 0 and horizon step 1 are read (WBC target assembly)
+  p.xref_steps = (!d_fsteps && d_x_f_mpc) ? 1 : 0;
   ctrl_common(h, cw, qrw::kCtrlWbcInputs);
   cw.in0 = d_x_f_mpc; cw.in1 = d_xref; cw.in2 = d_feet_pva; cw.in3 = d_v;
   cw.out0 = d_x_f_wbc; cw.out1 = d_q_wbc; cw.out2 = d_b_v; cw.out3 = d_f_cmd; cw.out4 = d_feet_cmd;

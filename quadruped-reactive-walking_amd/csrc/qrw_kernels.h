@@ -117,6 +117,7 @@ int sweeps_selftest(double* max_err);
 enum PlannerMode { kPlanInit = 1, kPlanGait = 2, kPlanFootsteps = 4, kPlanTraj = 8, kPlanState = 16, kPlanOutputs = 32 };
 struct PlannerArgs {
   int B, n_steps, N_gait, k_mpc, mode, k, k_footsteps, refresh, code_scalar, q_ld;
+  int xref_steps;  // horizon steps of xref to write (columns 1..xref_steps); 0 = all n_steps
   double dt_mpc, dt_wbc, T_gait, T_mpc, h_ref, k_feedback, g, L, max_height, lock_time, z_average;
   double shoulders[12], init_target[12], init_pos[12];
   const double *q7, *hv, *vref, *target_in;

@@ -465,9 +465,10 @@ class Batch:
         return x_f_mpc
 
     # ------------------------------------------------ fused control iteration (two launches + the MPC solve)
-    def control_pre(self, k, joy_v_ref, q_filt, v_filt, rpy, code=0, x_f_mpc=None, out=None):
+    def control_pre(self, k, joy_v_ref, q_filt, v_filt, rpy, code=0, x_f_mpc=None, out=None, mpc_inputs=True):
         """update_state + planner_step (+ controller_wbc_inputs when x_f_mpc is given) in one launch.
-        Returns one dict with the outputs of the three separate calls."""
+        Returns one dict with the outputs of the three separate calls.  mpc_inputs=False (an iteration that does not
+        solve, x_f_mpc given): `fsteps` and `gait` are not written and of `xref` only columns 0 and 1 are."""
         import torch
 
         B, N, Ng = self.B, self.N, self.N_gait
@@ -488,8 +489,9 @@ class Batch:
         _check(self._lib.qrw_control_pre(
             self._handle, int(k), d(joy_v_ref, (B, 6)), d(q_filt, (B, 19)), d(v_filt, (B, 18)), d(rpy, (B, 3)), cptr, cs, xf,
             d(out["q"], (B, 19)), d(out["v"], (B, 18)), d(out["h_v"], (B, 6)), d(out["v_ref"], (B, 6)),
-            d(out["oRh_oTh"], (B, 12)), d(out["xref"], (B, 12, N + 1)), d(out["fsteps"], (B, Ng, 12)),
-            d(out["gait"], (B, Ng, 4)), d(out["target"], (B, 3, 4)), d(out["feet_pva"], (B, 3, 3, 4)),
+            d(out["oRh_oTh"], (B, 12)), d(out["xref"], (B, 12, N + 1)),
+            d(out["fsteps"], (B, Ng, 12)) if mpc_inputs else _vp(0), d(out["gait"], (B, Ng, 4)) if mpc_inputs else _vp(0),
+            d(out["target"], (B, 3, 4)), d(out["feet_pva"], (B, 3, 3, 4)),
             d(out["contacts"], (B, 4)), d(out["x_f_wbc"], (B, 24)), d(out["q_wbc"], (B, 19)), d(out["b_v"], (B, 18)),
             d(out["f_cmd"], (B, 12)), d(out["feet_cmd"], (3, B, 3, 4)), self._stream()), "qrw_control_pre")
         return out

@@ -250,3 +250,42 @@ def test_async_free_running_startup_keeps_snapshots_intact():
         assert int((ctl.error_flag != 0).sum().item()) == 0
         assert bool(torch.isfinite(ctl._res["result"]).all())
         ctl.stop_parallel_loop()
+
+
+def test_control_pre_without_mpc_inputs_leaves_the_rest_unchanged():
+    """qrw_control_pre on an iteration that does not solve (d_fsteps / d_gait NULL, x_f_mpc given): fsteps and gait are not
+    written, of xref only column 0 and horizon step 1 are, and everything the WBC step reads is what the full call gives."""
+    import torch
+
+    import qrw_hip
+
+    B, N = 70, 16
+    rng = np.random.default_rng(21)
+    engs = [qrw_hip.Batch(B, N) for _ in range(2)]
+    for e in engs:
+        e.planner_init()
+        e.controller_init(_t(np.tile(Q_INIT, (B, 1))))
+    vref = _t(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0]))
+    qf = np.zeros((B, 19))
+    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+    x_f = np.zeros((B, 24, N))
+    x_f[:, 2, :], x_f[:, 14::3, :] = 0.2229, 6.0
+    outs = [None, None]
+    for k in range(1, 25):  # includes k = 10, 20: the lazy call is legal at any k, the caller decides
+        vf = np.zeros((B, 18))
+        vf[:, :6] = vref.cpu().numpy() + rng.uniform(-0.05, 0.05, (B, 6))
+        rpy = rng.uniform(-0.02, 0.02, (B, 3))
+        args = (k, vref, _t(qf), _t(vf), _t(rpy), 0)
+        outs[0] = engs[0].control_pre(*args, x_f_mpc=_t(x_f), out=outs[0])
+        if outs[1] is not None:
+            outs[1]["fsteps"].fill_(-7.0)
+            outs[1]["gait"].fill_(-7.0)
+            outs[1]["xref"][:, :, 2:].fill_(-7.0)
+        outs[1] = engs[1].control_pre(*args, x_f_mpc=_t(x_f), out=outs[1], mpc_inputs=False)
+        torch.cuda.synchronize()
+        full, lazy = outs
+        for key in ("q", "v", "h_v", "v_ref", "oRh_oTh", "target", "feet_pva", "contacts", "x_f_wbc", "q_wbc", "b_v", "f_cmd", "feet_cmd"):
+            assert torch.equal(full[key], lazy[key]), (k, key)
+        assert torch.equal(full["xref"][:, :, :2], lazy["xref"][:, :, :2])
+        if k > 1:
+            assert bool((lazy["fsteps"] == -7.0).all()) and bool((lazy["gait"] == -7.0).all()) and bool((lazy["xref"][:, :, 2:] == -7.0).all())
