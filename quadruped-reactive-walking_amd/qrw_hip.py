@@ -605,14 +605,16 @@ class StreamGroups:
         self._wbc_views = [{k: v[sl] for k, v in self.wbc_out.items()} for sl in self._sl]
 
     def control_step(self, xref, fsteps, num_iter, q, dq, contacts, pgoals, vgoals, agoals):
-        """One control step (MPC + WBC, 1:1) of the whole fleet; all inputs whole-fleet CUDA float64 tensors."""
+        """One control step (MPC + WBC, 1:1) of the whole fleet; all inputs whole-fleet CUDA float64 tensors
+        (num_iter: int, or CUDA int32 (B,) as for Batch.mpc_solve)."""
         import torch
 
         cur = torch.cuda.current_stream(self.device)
         for g, (eng, st, sl) in enumerate(zip(self.engines, self.streams, self._sl)):
             st.wait_stream(cur)  # inputs produced on the caller's stream are ready
             with torch.cuda.stream(st):
-                eng.mpc_solve(xref[sl], fsteps[sl], num_iter, out=self.mpc_out[sl])
+                eng.mpc_solve(xref[sl], fsteps[sl], num_iter[sl] if isinstance(num_iter, torch.Tensor) else num_iter,
+                              out=self.mpc_out[sl])
                 self.f_cmd[sl].copy_(self.mpc_out[sl][:, 12:, 0])
                 eng.wbc_compute(q[sl], dq[sl], self.f_cmd[sl], contacts[sl], pgoals[sl], vgoals[sl], agoals[sl],
                                 out=self._wbc_views[g])

@@ -312,7 +312,8 @@ def test_stream_groups_give_the_single_handle_results(synth_mod):
         d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sb.step(s).items() if k in keys}
         out = one.mpc_solve(d["xref"], d["fsteps"], s)
         ref = one.wbc_compute(d["q"], d["dq"], out[:, 12:, 0].contiguous(), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
-        res = grp.control_step(d["xref"], d["fsteps"], s, d["q"], d["dq"], d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+        ni = s if s % 2 == 0 else torch.full((B,), s, dtype=torch.int32, device="cuda")  # both forms of num_iter
+        res = grp.control_step(d["xref"], d["fsteps"], ni, d["q"], d["dq"], d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
         grp.synchronize()
         torch.cuda.synchronize()
         assert torch.equal(grp.mpc_out, out)
