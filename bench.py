@@ -93,11 +93,26 @@ def launch_ranks(args):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+    # a rank that dies early would leave the others waiting in the rendezvous: poll, and end the survivors (exact PIDs)
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(out0).decode())
     sys.stdout.flush()
-    return 0 if all(rc == 0 for rc in rcs) else 1
+    return 0 if (not failed and all(rc == 0 for rc in rcs)) else 1
 
 
 class StubEngine:
