@@ -5,11 +5,12 @@ sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd"), os.path.jo
 import numpy as np
 import oracle, qrw_hip, synth
 oracle.build(fast=False)
-B, N, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 16, 8
+B, N, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(os.environ.get("QRW_SOAK_N", "16")), 8
+NG = max(20, N + 4)
 gaits = ("trot", "walk", "bounding", "pacing") if len(sys.argv) > 2 else ("trot",)
-sb = synth.SyntheticBatch(B, N, gaits=gaits, n_seq=steps + 1, seed0=77000000)
-eng = qrw_hip.Batch(B, N)
-ref = oracle.MPCBatch(B, 0.02, N, 0.32, 20, fast=False)
+sb = synth.SyntheticBatch(B, N, N_gait=NG, gaits=gaits, n_seq=steps + 1, seed0=77000000)
+eng = qrw_hip.Batch(B, n_steps=N, N_gait=NG, T_gait=0.02 * N)
+ref = oracle.MPCBatch(B, 0.02, N, 0.02 * N, NG, fast=False)
 wref = oracle.WbcBatch(B, 0.002, fast=False)
 worst = worst_w = 0.0
 bad = 0
