@@ -83,8 +83,12 @@ int qrw_mpc_get_gait(qrw_handle h, int32_t b, double *h_gait, double *h_Sgait);
  * of an instance out when its call s has finished), so one instance's long solve delays nobody else's next call.  For
  * inputs that are all known beforehand — replaying the planner outputs a log holds (`planner_xref`, `planner_fsteps`,
  * scripts/LoggerControl.py:61-65,142-143) to recompute `mpc_x_f` (:76,:152), or open-loop evaluation sweeps — not for a
- * closed control loop, whose next inputs depend on this call's result.  qrw_mpc_sequence_error reports (after the stream
- * has been synchronised) whether the queue ever timed out (2 s without the awaited predecessor finishing; never expected). */
+ * closed control loop, whose next inputs depend on this call's result.  A diagnostic for an out-of-scope consumer (log
+ * replay), not part of the control path.  d_out is pre-filled with NaN and d_iters with -1, so a call that never ran cannot
+ * be mistaken for a result.  qrw_mpc_sequence_error synchronises the device and reports whether any workgroup gave up
+ * waiting for a task (2 s without ANY task of the sequence finishing -- the clock restarts on observed progress, so the
+ * length of K or of one instance's chain does not matter; never expected).  Forward progress assumes that workgroups of one
+ * launch start in index order (true of the hardware dispatcher; also on CU-masked streams, where fewer are resident). */
 int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double *d_xref, const double *d_fsteps, int32_t first_num_iter,
                            double *d_out, int32_t *d_iters, void *stream);
 int qrw_mpc_sequence_error(qrw_handle h, int32_t *timed_out);

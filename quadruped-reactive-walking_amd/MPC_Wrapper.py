@@ -194,6 +194,9 @@ class MPC_Wrapper_batch:
         instance only (qrw_mpc_solve_sequence); for inputs known beforehand, not for a closed loop.  The last call's
         result becomes the latest result."""
         res = self._b.mpc_solve_sequence(xref_log, fsteps_log, k0, out=out)
+        if self._b.mpc_sequence_timed_out():  # synchronises; calls that never ran are NaN in res
+            raise qrw_hip.QrwError("replay_batch: the sequence kernel's task queue gave up waiting (2 s without progress); "
+                                   "calls that did not run are NaN in the result")
         self._out = res[-1]
         return res
 

@@ -388,13 +388,34 @@ constexpr int kSeqLevels = 4;
 constexpr int kSeqStride = 16;                     // unsigned words per level in qctr
 static_assert(kSeqLevels * kSeqStride + 16 + kSeqLevels <= kSeqQctrWords, "qctr too small");
 constexpr int kSeqErr = kSeqLevels * kSeqStride;
-static_assert(kSeqErr == kSeqErrWord, "qrw_kernels.h and mpc_kernel.hip disagree on the queue counters' layout");   // error flag; + 1 diagnostics; + 2 + l: tasks through level l's queue; + 16 + l: its base
+static_assert(kSeqErr == kSeqErrWord, "qrw_kernels.h and mpc_kernel.hip disagree on the queue counters' layout");   // error flag; + 1 diagnostics; + 2 + l: tasks through level l's queue; + 8: finished tasks (progress); + 16 + l: its base
+constexpr int kSeqProgress = kSeqErr + 8;
 __device__ __forceinline__ unsigned q_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Give-up clock of a workgroup that waits for work.  It measures the time since the last OBSERVED PROGRESS of the whole
+// sequence (the finished-task counter), not since the workgroup started to look: at the tail of a long sequence the only
+// tasks left are the later calls of a few long chains (K calls x up to 4000 iterations x 2.3 us can be many seconds of serial
+// work), every other workgroup is resident and polling, and a clock started at workgroup start would make them exit without a
+// task -- calls that then never run.  A task ends at least every ~15 ms (4000 iterations at N = 32) while anything runs, so
+// 2 s without a single finished task means the queue is really stuck.  The counter is read only when the 2 s have passed.
+struct SeqGiveUp {
+  unsigned long long t0;
+  unsigned last;
+  const unsigned* prog;
+  __device__ __forceinline__ SeqGiveUp(const unsigned* p) : t0(__builtin_amdgcn_s_memrealtime()), last(q_load(p)), prog(p) {}
+  __device__ __forceinline__ bool expired() {
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    if (now - t0 <= 200000000ull) return false;
+    const unsigned p = q_load(prog);
+    if (p != last) { last = p; t0 = now; return false; }
+    return true;
+  }
+};
 template <int NW>
 __device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long long* sh, int tid, bool first_pass) {
   int task = -1;
   if (tid == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    const unsigned long long t_look = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    SeqGiveUp clock(&a.qctr[kSeqProgress]);
     if (first_pass) task = a.seq_first[blockIdx.x];  // dealt by workgroup index (the init kernel left these out of the queues)
     bool give_up = first_pass;
     while (task < 0 && !give_up) {
@@ -414,7 +435,7 @@ __device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long lon
             task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (task >= 0) break;
             __builtin_amdgcn_s_sleep(32);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: the task never came; give up, loudly
+            if (clock.expired()) {  // 2 s without any task of the sequence finishing: the task never came; give up, loudly
               __hip_atomic_store(&a.qctr[kSeqErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               give_up = true;
               break;
@@ -424,7 +445,7 @@ __device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long lon
       }
       if (task >= 0 || all_done) break;
       __builtin_amdgcn_s_sleep(127);  // upper levels empty right now and the lowest one exhausted: look again in a few microseconds
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+      if (clock.expired()) {
         __hip_atomic_store(&a.qctr[kSeqErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         give_up = true;
       }
@@ -434,7 +455,7 @@ __device__ __forceinline__ int seq_next_task(const MpcArgs& a, unsigned long lon
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef QRW_SEQ_STATS  // diagnostics: 100 MHz ticks spent looking for work, summed over the workgroups
-    __hip_atomic_fetch_add(&a.qctr[kSeqErr + 1], (unsigned)(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&a.qctr[kSeqErr + 1], (unsigned)(__builtin_amdgcn_s_memrealtime() - t_look), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   }
   if constexpr (NW == 1) {
@@ -453,6 +474,7 @@ template <int NW>
 __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq_s, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of the instance's state and results have left
   if constexpr (NW > 1) __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(&a.qctr[kSeqProgress], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // SeqGiveUp's clock
   if (tid == 0 && seq_s + 1 < a.seq_K) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -482,9 +504,15 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const int lane = tid & 63, wv = tid >> 6;
   {
   int b, seq_s = 0;
+#ifdef QRW_SEQ_STATS
+  unsigned long long task_t0 = 0;
+#endif
   if constexpr (SEQ) {
     const int task = seq_next_task<NW>(a, &L.sBal[0], tid, (int)blockIdx.x < a.seq_groups);
     if (task < 0) return;  // the queue timed out (the error flag in a.qctr is set)
+#ifdef QRW_SEQ_STATS
+    task_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     seq_s = task / a.B;
     b = task - seq_s * a.B;
   } else {
@@ -1425,6 +1453,7 @@ __global__ void mpc_seq_init_kernel(int* queue, unsigned* qctr, int* level, int*
     }
     qctr[kSeqErr] = 0u;
     qctr[kSeqErr + 1] = 0u;
+    qctr[kSeqProgress] = 0u;
   }
 }
 

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -126,7 +127,8 @@ static void base_inertia_diag(double Y[6]) {
 // 54-62: height 0.2447..., feet at (+-0.195, +-0.147)), first MPC call, N = 16.  Expected values recorded from the CPU
 // restatement (oracle/, 2026-10): 350 ADMM iterations (one rho adaptation at iteration 200), rho 1.03905792582975e-3,
 // four equal vertical forces summing to 24.5347812847 N (m g = 24.525 N), horizontal forces zero.
-static int mpc_known_answer_check(double* worst) {
+struct KatResult { int iters = -1, status = 0; double err = 0.0, rho = 0.0; };
+static int mpc_known_answer_check(KatResult* res) {
   constexpr int N = 16, Ng = 20, T = 64;
   double hx[12 * (N + 1)] = {0}, hf[Ng * 12] = {0}, hout[24 * N];
   for (int c = 0; c <= N; c++) hx[2 * (N + 1) + c] = 0.24474949993103629;
@@ -139,12 +141,14 @@ static int mpc_known_answer_check(double* worst) {
       hipMalloc(&bst.p, qrw::kMpcStItems * T * sizeof(double)) != hipSuccess || hipMalloc(&bg.p, Ng * 4 * sizeof(int)) != hipSuccess ||
       hipMalloc(&bi.p, n_int * sizeof(int)) != hipSuccess || hipMalloc(&bd.p, n_dbl * sizeof(double)) != hipSuccess)
     return -10;
+  // blocking copies / memsets on the null stream of pageable host memory: complete when they return
   hipMemcpy(bx.p, hx, sizeof(hx), hipMemcpyHostToDevice);
   hipMemcpy(bf.p, hf, sizeof(hf), hipMemcpyHostToDevice);
   hipMemset(bst.p, 0, qrw::kMpcStItems * T * sizeof(double));
   hipMemset(bg.p, 0, Ng * 4 * sizeof(int));
   hipMemset(bi.p, 0, n_int * sizeof(int));
   hipMemset(bd.p, 0, n_dbl * sizeof(double));
+  hipStreamSynchronize(nullptr);
   qrw::MpcArgs a;
   memset(&a, 0, sizeof(a));
   a.B = 1; a.N = N; a.N_gait = Ng; a.dt = 0.02;
@@ -153,12 +157,15 @@ static int mpc_known_answer_check(double* worst) {
   int* ip = (int*)bi.p; double* dp = (double*)bd.p;
   a.flags = ip; a.iters = ip + 1; a.status = ip + 2; a.rho_updates = ip + 3;
   a.rho_out = dp; a.pri = dp + 1; a.dua = dp + 2; a.prof = nullptr; a.order = nullptr;
-  if (qrw::mpc_launch(a, nullptr) != 0) return -11;
-  if (hipDeviceSynchronize() != hipSuccess) return -12;
+  // a private non-blocking stream: the check neither waits for nor stalls the work other streams of the process have queued
+  struct Stream { hipStream_t s = nullptr; ~Stream() { if (s) hipStreamDestroy(s); } } st;
+  if (hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) != hipSuccess) return -10;
+  if (qrw::mpc_launch(a, st.s) != 0) return -11;
   int hi[n_int]; double hd[n_dbl];
-  hipMemcpy(hi, bi.p, sizeof(hi), hipMemcpyDeviceToHost);
-  hipMemcpy(hd, bd.p, sizeof(hd), hipMemcpyDeviceToHost);
-  hipMemcpy(hout, bo.p, sizeof(hout), hipMemcpyDeviceToHost);
+  hipMemcpyAsync(hi, bi.p, sizeof(hi), hipMemcpyDeviceToHost, st.s);
+  hipMemcpyAsync(hd, bd.p, sizeof(hd), hipMemcpyDeviceToHost, st.s);
+  hipMemcpyAsync(hout, bo.p, sizeof(hout), hipMemcpyDeviceToHost, st.s);
+  if (hipStreamSynchronize(st.s) != hipSuccess) return -12;
   double err = 0.0, fz = 0.0;
   for (int j = 0; j < 4; j++) {
     fz += hout[(12 + 3 * j + 2) * N];
@@ -168,20 +175,33 @@ static int mpc_known_answer_check(double* worst) {
   err = fmax(err, fabs(fz - 24.534781284726584));
   err = fmax(err, fabs(hd[0] / 1.0390579258297492e-3 - 1.0));
   if (!(err == err)) err = 1e300;  // NaN
-  if (worst) *worst = err;
-  return (hi[1] == 350 && hi[2] == qrw::kStatusSolved && err < 1e-8) ? 0 : 1;
+  if (res) { res->iters = hi[1]; res->status = hi[2]; res->err = err; res->rho = hd[0]; }
+  // The pass criterion is the ANSWER (status solved, forces and rho to 1e-8).  The iteration count is reported, and
+  // only checked loosely: 350 with the shipped toolchain; a legitimate compiler change may move a borderline termination
+  // test by one check interval (25), a miscompiled kernel diverges (status != solved) or lands far away.
+  return (hi[2] == qrw::kStatusSolved && err < 1e-8 && hi[1] >= 300 && hi[1] <= 400) ? 0 : 1;
 }
-static int g_kat_state[64] = {0};  // per device: 0 not run, 1 passed, -1 failed
+// per device: 0 not run, 1 passed, -1 failed; guarded by a mutex (qrw_create may be called from several threads)
+static std::mutex g_kat_mutex;
+static int g_kat_state[64] = {0};
+static KatResult g_kat_result[64];
 static int mpc_known_answer_once(int device) {
   if (device < 0 || device >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_kat_mutex);
   if (g_kat_state[device] == 0 && qrw::mpc_build_is_timing_experiment()) {
     fprintf(stderr, "libqrw_hip: TIMING-EXPERIMENT BUILD (wrong results by construction), self-test skipped\n");
     g_kat_state[device] = 1;
   }
   if (g_kat_state[device] == 0) {
-    double w = 0.0;
-    const int rc = mpc_known_answer_check(&w);
-    g_kat_state[device] = (rc == 0) ? 1 : -1;
+    const char* skip = getenv("QRW_SKIP_SELFTEST");  // escape hatch (e.g. bring-up on a new toolchain): say so, loudly
+    if (skip && skip[0] == '1') {
+      fprintf(stderr, "libqrw_hip: QRW_SKIP_SELFTEST=1, the known-answer self-test of mpc_solve_kernel is SKIPPED\n");
+      g_kat_state[device] = 1;
+    } else {
+      const int rc = mpc_known_answer_check(&g_kat_result[device]);
+      if (rc < 0) g_kat_result[device].status = rc;
+      g_kat_state[device] = (rc == 0) ? 1 : -1;
+    }
   }
   return g_kat_state[device] == 1 ? 0 : 1;
 }
@@ -197,10 +217,16 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
     return fail(-2, "qrw_create: no HIP device (this library has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(-2, "qrw_create: bad device ordinal");
   DeviceScope dev_scope__(cfg->device);
-  if (mpc_known_answer_once(cfg->device) != 0)
-    return fail(-20, "qrw_create: the known-answer self-test of mpc_solve_kernel failed on this device: this build of libqrw_hip.so "
-                     "computes wrong results (a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild "
-                     "with the Makefile's flags");
+  if (mpc_known_answer_once(cfg->device) != 0) {
+    const KatResult& r = g_kat_result[cfg->device];
+    char msg[512];
+    snprintf(msg, sizeof(msg),
+             "qrw_create: the known-answer self-test of mpc_solve_kernel failed on this device (got %d ADMM iterations, status %d, "
+             "rho %.10g, error %.3g; expected 350, solved, 1.0390579258e-3, < 1e-8): this build of libqrw_hip.so computes wrong results "
+             "(a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild with the Makefile's flags "
+             "(QRW_SKIP_SELFTEST=1 skips this check)", r.iters, r.status, r.rho, r.err);
+    return fail(-20, msg);
+  }
   qrw_handle h = new qrw_handle_s();
   h->cfg = *cfg;
   const size_t B = (size_t)cfg->batch;
@@ -322,7 +348,13 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
     if (hipMalloc((void**)&h->seq_hot, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc hot flags");
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device), "hipGetDeviceProperties");
-    // resident workgroups: one 512-register wavefront per SIMD (N <= 16: 4 workgroups per CU; N > 16: 2 of two wavefronts)
+    // resident workgroups: one 512-register wavefront per SIMD (N <= 16: 4 workgroups per CU; N > 16: 2 of two wavefronts).
+    // Only a scheduling hint: the first seq_groups workgroups take call 0 of the seq_groups longest-ranked instances by
+    // index instead of through the queues.  On a CU-masked stream (or beside another stream group) fewer workgroups are
+    // resident at a time; the dealt ones then simply start in several rounds.  What forward progress does rest on is that
+    // workgroups START IN INDEX ORDER (every workgroup with a dealt task starts before any queue-fed one can hold the
+    // last free slot) -- how the hardware dispatcher works, and what the one-call kernel's longest-first order already
+    // assumes; tests/test_gpu_mpc.py runs a sequence on a masked stream beside a second stream to pin it.
     h->seq_groups = prop.multiProcessorCount * (h->cfg.n_steps <= 16 ? 4 : 2);
   }
   qrw::MpcArgs a;
@@ -336,6 +368,10 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
   a.order = h->mpc_have_order ? h->mpc_order : nullptr;
   a.seq_K = K; a.queue = h->seq_queue; a.qctr = h->seq_ctr; a.seq_hot = h->seq_hot; a.seq_first = h->seq_first; a.seq_iters = d_iters;
   a.seq_groups = h->seq_groups < h->cfg.batch ? h->seq_groups : h->cfg.batch;
+  // a task that never runs (queue give-up, see qrw_mpc_sequence_error) must not leave plausible numbers behind: results
+  // are pre-filled with NaN (all-ones bytes) and the iteration counts with -1
+  HIP_OK(hipMemsetAsync(d_out, 0xFF, need * 24 * (size_t)h->cfg.n_steps * sizeof(double), (hipStream_t)stream), "qrw_mpc_solve_sequence prefill");
+  if (d_iters) HIP_OK(hipMemsetAsync(d_iters, 0xFF, need * sizeof(int32_t), (hipStream_t)stream), "qrw_mpc_solve_sequence prefill iters");
   if (qrw::mpc_sequence_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_mpc_solve_sequence: kernel launch failed", hipGetLastError());
   if (h->cfg.batch > 1024) {
@@ -351,6 +387,8 @@ extern "C" int qrw_mpc_sequence_error(qrw_handle h, int32_t* timed_out) {
   DeviceScope dev_scope__(h->cfg.device);
   *timed_out = 0;
   if (!h->seq_ctr) return 0;
+  // like every other getter: streams of qrw_stream_create are non-blocking, a plain copy would not wait for a sequence in flight
+  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_sequence_error sync");
   unsigned c[qrw::kSeqQctrWords];
   HIP_OK(hipMemcpy(c, h->seq_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_sequence_error");
   *timed_out = (int32_t)c[qrw::kSeqErrWord];
@@ -639,9 +677,14 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_sweeps: no HIP device");
   const int rc = qrw::sweeps_selftest(max_err);
   if (rc != 0) return rc;
-  double kat_err = 0.0;
-  const int krc = mpc_known_answer_check(&kat_err);  // the whole solve, not only its sweeps
-  if (krc != 0) return fail(2, "qrw_selftest_sweeps: known-answer MPC solve failed");
+  KatResult kat;
+  const int krc = mpc_known_answer_check(&kat);  // the whole solve, not only its sweeps
+  if (krc != 0) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "qrw_selftest_sweeps: known-answer MPC solve failed (rc %d: %d iterations, status %d, rho %.10g, error %.3g)",
+             krc, kat.iters, kat.status, kat.rho, kat.err);
+    return fail(2, msg);
+  }
   return 0;
 }
 

@@ -261,7 +261,8 @@ class Batch:
         return out
 
     def mpc_sequence_timed_out(self):
-        """After synchronising: True if the sequence kernel's task queue ever gave up waiting (never expected)."""
+        """Synchronises the device; True if the sequence kernel's task queue ever gave up waiting (never expected; the
+        calls that did not run are NaN in `out` and -1 in `iters`)."""
         v = C.c_int32(0)
         _check(self._lib.qrw_mpc_sequence_error(self._handle, C.byref(v)), "qrw_mpc_sequence_error")
         return bool(v.value)

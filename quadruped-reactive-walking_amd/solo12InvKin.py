@@ -32,11 +32,6 @@ class Solo12InvKin:
         self.foot_ids = np.array([10, 18, 26, 34])
         self.BASE_ID = self.foot_ids[0]
 
-    def cross3(self, left, right):
-        return np.array([left[1] * right[2] - left[2] * right[1],
-                         left[2] * right[0] - left[0] * right[2],
-                         left[0] * right[1] - left[1] * right[0]])
-
     def refreshAndCompute(self, q, dq, contacts, pgoals, vgoals, agoals):
         q12 = np.asarray(q, dtype=np.float64).reshape(12)
         dq12 = np.asarray(dq, dtype=np.float64).reshape(12)

@@ -424,3 +424,70 @@ def test_sequence_launch_equals_consecutive_calls(synth_mod, N, B, K, gaits):
     r2 = [a.mpc_solve(xs[s], fs[s], K + 1 + s).cpu().numpy() for s in range(2)]
     torch.cuda.synchronize()
     assert np.array_equal(o2.cpu().numpy(), np.stack(r2)) and not b.mpc_sequence_timed_out()
+
+
+def test_sequence_tail_longer_than_the_give_up_clock(synth_mod):
+    """the sequence kernel's 2 s give-up clock must count from the last observed progress, not from the
+    moment a workgroup starts to look for work.  One NaN-poisoned instance runs max_iter (4000) iterations on every call:
+    with K = 260 calls its chain alone is ~2.6 s of serial work, during which every other workgroup of the launch is
+    resident and polling.  No workgroup may give up, every call of every instance must have run (no NaN pre-fill left,
+    no -1 iteration count), and the healthy instances must get what consecutive calls give."""
+    import torch
+
+    import qrw_hip
+
+    N, B, K = 16, 6, 260
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot",), seed0=20290000)
+    d = [sb.step(s) for s in range(4)]
+    dev = torch.device("cuda", 0)
+    xs = torch.from_numpy(np.stack([d[s % 4]["xref"] for s in range(K)])).to(dev)
+    fs = torch.from_numpy(np.stack([d[s % 4]["fsteps"] for s in range(K)])).to(dev)
+    xs[:, 2, 7, 3] = float("nan")  # instance 2: a NaN in its reference trajectory, every call
+    a, b = (qrw_hip.Batch(B, n_steps=N) for _ in range(2))
+    its = torch.zeros((K, B), dtype=torch.int32, device=dev)
+    t0 = __import__("time").perf_counter()
+    out = b.mpc_solve_sequence(xs, fs, 0, iters=its)
+    torch.cuda.synchronize()
+    el = __import__("time").perf_counter() - t0
+    assert not b.mpc_sequence_timed_out()
+    it = its.cpu().numpy()
+    assert (it[:, 2] == 4000).all() and (it > 0).all(), it[:3]
+    o = out.cpu().numpy()
+    healthy = [0, 1, 3, 4, 5]
+    assert np.isfinite(o[:, healthy]).all()
+    print("sequence of %d calls with one max-iter chain: %.2f s" % (K, el))
+    assert el > 2.0, "the chain was meant to outlast the 2 s clock (%.2f s): raise K" % el
+    for s in range(12):  # the healthy instances against ordinary calls (a prefix is enough: same code path as the parity test)
+        r = a.mpc_solve(xs[s], fs[s], s).cpu().numpy()
+        assert np.array_equal(r[healthy], o[s, healthy]), s
+
+
+def test_sequence_on_a_masked_stream_beside_another_stream_group(synth_mod):
+    """seq_groups is sized from the whole device, but a sequence may run on a CU-masked stream or beside
+    another stream's solves, where fewer workgroups are resident than dealt call-0 tasks.  Results must not change."""
+    import torch
+
+    import qrw_hip
+
+    N, B, K = 16, 700, 4
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=20291000)
+    steps = [sb.step(s) for s in range(K)]
+    dev = torch.device("cuda", 0)
+    xs = torch.from_numpy(np.stack([st["xref"] for st in steps])).to(dev)
+    fs = torch.from_numpy(np.stack([st["fsteps"] for st in steps])).to(dev)
+    a, b, c = (qrw_hip.Batch(B, n_steps=N) for _ in range(3))
+    ref = np.stack([a.mpc_solve(xs[s], fs[s], s).cpu().numpy() for s in range(K)])
+    n_cu = qrw_hip.device_cu_count(0)
+    masked = qrw_hip.CuStream(0, 0, 64)          # 64 of the compute units: 256 resident workgroups for 700 dealt tasks
+    other = qrw_hip.CuStream(0, 64, n_cu - 64)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(other.torch):          # a second group's solves in flight on the other units
+        for s in range(K):
+            c.mpc_solve(xs[s], fs[s], s)
+    with torch.cuda.stream(masked.torch):
+        out = b.mpc_solve_sequence(xs, fs, 0)
+    torch.cuda.synchronize()
+    assert not b.mpc_sequence_timed_out()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    masked.close()
+    other.close()
