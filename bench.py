@@ -73,6 +73,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective", action="store_true", help="N > 1: skip the per-step all-gather of torques")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the in-line legs of the other BASELINE configurations "
+                    "(batch 1, batch 256 MPC-only, batch 4096 N=32 mixed gaits)")
+    ap.add_argument("--dry-ranks", type=int, default=0, metavar="N",
+                    help="multi-GPU pre-flight on ONE GPU: walk every per-rank code path of --gpus N (handle creation + "
+                         "self-test, this rank's shard of the inputs, a short timed region, JSON assembly) for LOCAL_RANK = "
+                         "0..N-1, one rank at a time, all mapped to device 0; prints one line with per-rank figures")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="instances in the CPU baseline / accuracy sample")
     ap.add_argument("--cpu-steps", type=int, default=24, help="control steps of the CPU baseline / accuracy sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16 cores)")
@@ -146,6 +152,8 @@ class StubEngine:
 
 def main():
     args = parse_args()
+    if args.dry_ranks > 0:
+        raise SystemExit(dry_ranks(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,7 +202,9 @@ def main():
     collective = multi and not args.no_collective
     n_regions = 2 if collective else 1      # N > 1: a second timed region without the all-gather, same line
     n_in = W + n_regions * K
-    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=n_in, b0=rank * B)
+    # --dry-ranks: this process stands in for rank QRW_DRY_RANK of a QRW_DRY_WORLD-rank job (its shard of the instances)
+    shard_rank = int(os.environ.get("QRW_DRY_RANK", rank))
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=n_in, b0=shard_rank * B)
     t_gen = time.time()
     steps = [sb.step(s) for s in range(n_in)]
     t_gen = time.time() - t_gen
@@ -206,11 +216,13 @@ def main():
     q, dq, contacts = dev_t("q"), dev_t("dq"), dev_t("contacts")
     pg, vg, ag = dev_t("pgoals"), dev_t("vgoals"), dev_t("agoals")
 
+    t_create = time.time()
     if stub:
         eng = StubEngine(B, N, rank * B, torch)
     else:
         import qrw_hip
         eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=local_rank)
+    t_create = time.time() - t_create  # includes this process's known-answer self-test of the kernel (first handle on the device)
     mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
     f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
     wbc_bufs = [None, None]  # two output sets: the gather of step s reads one while step s+1 writes the other
@@ -323,6 +335,9 @@ def main():
         out["solver"] = {"mpc_solved_last_step": int((ms["status"] == 1).sum()), "mpc_instances": B,
                          "wbc_mean_iters": float(ws["iters"].mean())}
         out["input_gen_s"] = t_gen
+        out["handle_create_s"] = t_create
+        out["device_ordinal"] = local_rank
+        out["shard_first_instance"] = shard_rank * B
     if rank == 0 and world == 1 and not stub:
         out["mpc_solves_per_s"] = B * K / (mpc_ms.sum() * 1e-3)
         out["wbc_steps_per_s"] = B * K / (wbc_ms.sum() * 1e-3)
@@ -334,6 +349,11 @@ def main():
             out["closed_loop_sequence"] = closed_loop_sequence(B, N, N_gait, gaits, dev, W, K)
             out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
+        if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
+            # the metric reads "batch {1, 256, 4096}" and BASELINE lists configs 2 and 4: every single-GPU figure in this ONE line
+            out["batch_1"] = config_leg(1, 16, ("trot",), dev, W=3, K=20)
+            out["batch_256_mpc_only"] = config_leg(256, 16, ("trot",), dev, W=3, K=20, mpc_only=True)
+            out["config4_n32_mixed"] = config_leg(4096, 32, ("walk", "trot", "bounding"), dev, W=3, K=6, closed=True, groups=2)
         if not args.no_cpu_baseline:
             base, ref_out = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
             out["cpu_baseline"] = base
@@ -345,26 +365,192 @@ def main():
         dist.destroy_process_group()
 
 
+def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0):
+    """One BASELINE configuration other than the headline's, timed in-line on a FRESH handle with the headline's method:
+    W untimed warm-up steps (the first one sets the QPs up), K timed steps bracketed by synchronisation, HIP events around
+    every mpc_solve launch, the ADMM iteration counts of every timed launch (device-to-device), FP64 fraction with THIS
+    horizon's work terms.  closed=True adds SURVEY 8(d)'s closed receding-horizon variant of the same configuration (inputs
+    generated by an untimed pass, replayed from HBM on a fresh handle), groups=S the open-loop workload as S stream groups."""
+    import torch
+
+    import qrw_hip
+    import synth
+
+    N_gait = max(20, N + 4)
+    mk = dict(n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    keys = ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")
+
+    def to_dev(d):
+        return {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in keys}
+
+    def timed(seq, label):
+        eng = qrw_hip.Batch(B, **mk)
+        mpc_out = torch.empty((B, 24, N), dtype=torch.float64, device=dev)
+        f_cmd = torch.empty((B, 12), dtype=torch.float64, device=dev)
+        it_dev = torch.zeros((K, B), dtype=torch.int32, device=dev)
+        st_dev = torch.zeros((K, B), dtype=torch.int32, device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        w = None
+
+        def step(s, i=None):
+            nonlocal w
+            t = seq[s]
+            if i is not None:
+                ev[i][0].record()
+            eng.mpc_solve(t["xref"], t["fsteps"], s, out=mpc_out)
+            if i is not None:
+                ev[i][1].record()
+            if not mpc_only:
+                f_cmd.copy_(mpc_out[:, 12:, 0])
+                w = eng.wbc_compute(t["q"], t["dq"], f_cmd, t["contacts"], t["pgoals"], t["vgoals"], t["agoals"], out=w)
+            if i is not None:
+                eng.copy_mpc_iters(it_dev[i])
+
+        for s in range(W):
+            step(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(W + i, i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ms = np.array([a.elapsed_time(b) for a, b in ev])
+        iters = it_dev.cpu().numpy().astype(np.float64)
+        status = eng.mpc_stats()["status"]
+        eng.close()
+        flops = iters.sum() * f_iter(N) + K * B * (f_fac(N) + F_ASM)
+        return {"value": B * K / el, "unit": "MPC solves/s" if mpc_only else "steps/s", "ms_per_step": 1e3 * el / K,
+                "launch_ms_mean": float(ms.mean()), "mean_admm_iters": float(iters.mean()), "max_admm_iters": int(iters.max()),
+                "max_iter_exit_share": float((iters >= 4000).mean()),
+                "solved_share_last_step": float((status == 1).mean()),
+                "roofline_frac": float(flops / (ms.sum() * 1e-3) / PEAK_FP64), "flops_per_iteration": f_iter(N),
+                "timed_steps": K, "warmup_steps": W, "sequence": label}
+
+    sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K)
+    seq = [to_dev(sb.step(s)) for s in range(W + K)]
+    res = timed(seq, "open-loop noisy states (as the headline)")
+    res["workload"] = "Solo12 %s, batch %d, horizon N=%d, %s" % ("/".join(gaits), B, N, "MPC only" if mpc_only else "MPC + WBC 1:1")
+    if groups and B % groups == 0:
+        grp = qrw_hip.StreamGroups(B, groups=groups, **mk)
+
+        def gstep(s):
+            t = seq[s]
+            grp.control_step(t["xref"], t["fsteps"], s, t["q"], t["dq"], t["contacts"], t["pgoals"], t["vgoals"], t["agoals"])
+
+        for s in range(W):
+            gstep(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            gstep(W + i)
+        torch.cuda.synchronize()
+        res["stream_groups_%d_steps_per_s" % groups] = B * K / (time.perf_counter() - t0)
+        grp.close()
+    if closed:
+        gen = qrw_hip.Batch(B, **mk)
+        sbc = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K)
+        cseq, x0 = [], None
+        for s in range(W + K):
+            t = to_dev(sbc.step(s, x0))
+            x0 = gen.mpc_solve(t["xref"], t["fsteps"], s)[:, :12, 0].cpu().numpy()
+            cseq.append(t)
+        gen.close()
+        c = timed(cseq, "closed receding-horizon sequence (SURVEY 8(d))")
+        res["closed_loop"] = {k: c[k] for k in ("value", "unit", "ms_per_step", "launch_ms_mean", "mean_admm_iters", "max_admm_iters",
+                                                "max_iter_exit_share", "roofline_frac")}
+    return res
+
+
+def dry_ranks(args):
+    """`--dry-ranks N`: the multi-GPU pre-flight of VERDICT r2 item 7.  No 8-GPU node is available to the build, so a first
+    SCALE run must not fail on plumbing: for LOCAL_RANK = 0..N-1, ONE RANK AT A TIME (a 1-GPU box allows few processes on
+    its card), start this script as that rank of an N-rank job with every rank mapped to device 0 and a single-rank process
+    group (the real nccl init / barrier / all_gather_into_tensor / all_reduce calls of the N > 1 branch run, on one rank).
+    Each child walks the rank's whole path -- qrw_create + known-answer self-test, ITS shard of the synthetic inputs
+    (b0 = rank * batch), warm-up, both timed regions, JSON assembly -- and prints its line; this parent collects them."""
+    import socket
+
+    n = int(args.dry_ranks)
+    per_rank = []
+    t_all = time.time()
+    for r in range(n):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, QRW_DRY_RANK=str(r), QRW_DRY_WORLD=str(n), QRW_SINGLE_DEVICE="1", QRW_FORCE_COLLECTIVE="1",
+                   RANK="0", LOCAL_RANK=str(r), WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        argv = [a for a in sys.argv[1:]]
+        for i, a in enumerate(argv):  # drop the --dry-ranks flag (and its value)
+            if a == "--dry-ranks":
+                del argv[i:i + 2]
+                break
+            if a.startswith("--dry-ranks="):
+                del argv[i]
+                break
+        argv += ["--gpus", "1", "--no-secondary", "--no-configs", "--no-cpu-baseline"]
+        t0 = time.time()
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, env=env, capture_output=True, text=True)
+        wall = time.time() - t0
+        line = None
+        for ln in p.stdout.splitlines():
+            if ln.startswith("{"):
+                line = json.loads(ln)
+        if p.returncode != 0 or line is None:
+            sys.stderr.write(p.stderr[-2000:])
+            print(json.dumps({"dry_ranks": n, "failed_rank": r, "rc": p.returncode}), flush=True)
+            return 1
+        per_rank.append({"local_rank": r, "device_ordinal_used": line.get("device_ordinal"), "shard_first_instance": line.get("shard_first_instance"),
+                         "steps_per_s": line["value"], "launch_ms_mean": line["roofline"]["launch_ms_mean"],
+                         "input_gen_s": line.get("input_gen_s"), "handle_create_s": line.get("handle_create_s"),
+                         "ranks_seen": line.get("collective", {}).get("ranks_seen"),
+                         "gathered_block_check": line.get("collective", {}).get("gathered_block_check"),
+                         "backend": line.get("collective", {}).get("backend"), "process_wall_s": wall})
+    print(json.dumps({"dry_ranks": n, "what": "per-rank pre-flight of --gpus %d on one GPU: every rank's path walked one rank at a time on "
+                      "device 0 with a one-rank RCCL group; NOT a scaling measurement" % n, "batch_per_rank": args.batch,
+                      "n_steps": args.n_steps, "steps": args.steps, "per_rank": per_rank, "total_wall_s": time.time() - t_all}), flush=True)
+    return 0
+
+
+def mpc_source_stamp():
+    """sha256 over the sources that decide mpc_solve_kernel's HBM traffic (the kernel, its sweeps, the state layout)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("mpc_kernel.hip", "chain_sweep.h", "qrw_kernels.h", "qrw_device.h"):
+        h.update(open(os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic_bytes(B, N):
     """HBM bytes per mpc_solve_kernel launch.  NOT measured by this run: read from the committed rocprofv3 PMC passes of
     this same command (profiles/, separate --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE are in
     KiB; the kernel's accesses are 8 bytes per lane, a width the guide marks uncalibrated on gfx950, so no correction
-    factor is applied).  Only valid for the profiled shape (batch 4096, N = 16)."""
+    factor is applied).  Only valid for the profiled shape (batch 4096, N = 16) AND the profiled kernel: the summary carries
+    a stamp of the kernel's sources (scripts/pmc_profile.sh writes it), and a summary whose stamp differs from the sources
+    this run was built from is refused (traffic null) instead of silently going stale."""
     if (B, N) != (4096, 16):
         return None, None
-    for name in ("r2_pmc_summary_bench_b4096.json", "r1_pmc_summary_bench_b4096.json"):
+    now = mpc_source_stamp()
+    refused = []
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary_bench_b4096.json")), reverse=True):
         path = os.path.join(ROOT, "profiles", name)
         try:
             rows = json.load(open(path))
+            stamp = json.load(open(path.replace("_pmc_summary_", "_pmc_stamp_"))).get("mpc_source_sha256")
         except Exception:
+            refused.append("%s: no source stamp" % name)
+            continue
+        if stamp != now:
+            refused.append("%s: collected on other kernel sources" % name)
             continue
         tot = 0.0
         for r in rows:
             if "mpc_solve_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot += r["mean"] * 1024.0
         if tot:
-            return tot, "profiles/%s (static: rocprofv3 --pmc passes of this command, not collected by this run)" % name
-    return None, None
+            return tot, "profiles/%s (static: rocprofv3 --pmc passes of this command on these kernel sources, not collected by this run)" % name
+    return None, "refused: " + "; ".join(refused) if refused else None
 
 
 def stream_groups_figure(B, N, N_gait, dev, W, K, data, S=2):

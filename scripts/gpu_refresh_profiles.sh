@@ -3,7 +3,7 @@
 # ROUND tags the file names (profiles/ keeps one set per round).
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r2}
+ROUND=${ROUND:-r3}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd $R
@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32 -o st -- py
 cp $(find $OUT/stats32 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_n32_mixed.csv
 cp $(find $OUT/stats32 -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_n32.csv
 echo "rocprof stats done"
-cd $R && ROUND=$ROUND bash scripts/pmc_profile.sh > $OUT/pmc.log 2>&1 && cp $R/gpurun_out/pmc_$ROUND/summary.json $OUT/${ROUND}_pmc_summary_bench_b4096.json
+cd $R && ROUND=$ROUND bash scripts/pmc_profile.sh > $OUT/pmc.log 2>&1 && cp $R/gpurun_out/pmc_$ROUND/summary.json $OUT/${ROUND}_pmc_summary_bench_b4096.json && cp $R/gpurun_out/pmc_$ROUND/stamp.json $OUT/${ROUND}_pmc_stamp_bench_b4096.json
 echo "pmc done"
 python3 scripts/trace_timed_avg.py $OUT/kernel_trace_b4096.csv 20 > $OUT/${ROUND}_timed_launch_avg_b4096.txt
 python3 scripts/trace_timed_avg.py $OUT/kernel_trace_n32.csv 20 > $OUT/${ROUND}_timed_launch_avg_n32.txt
