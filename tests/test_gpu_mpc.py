@@ -429,20 +429,20 @@ def test_sequence_launch_equals_consecutive_calls(synth_mod, N, B, K, gaits):
 def test_sequence_tail_longer_than_the_give_up_clock(synth_mod):
     """the sequence kernel's 2 s give-up clock must count from the last observed progress, not from the
     moment a workgroup starts to look for work.  One NaN-poisoned instance runs max_iter (4000) iterations on every call:
-    with K = 260 calls its chain alone is ~2.6 s of serial work, during which every other workgroup of the launch is
+    with K = 300 calls its chain alone is ~2.7 s of serial work, during which every other workgroup of the launch is
     resident and polling.  No workgroup may give up, every call of every instance must have run (no NaN pre-fill left,
     no -1 iteration count), and the healthy instances must get what consecutive calls give."""
     import torch
 
     import qrw_hip
 
-    N, B, K = 16, 6, 260
+    N, B, K = 16, 6, 300
     sb = synth_mod.SyntheticBatch(B, N, gaits=("trot",), seed0=20290000)
     d = [sb.step(s) for s in range(4)]
     dev = torch.device("cuda", 0)
     xs = torch.from_numpy(np.stack([d[s % 4]["xref"] for s in range(K)])).to(dev)
     fs = torch.from_numpy(np.stack([d[s % 4]["fsteps"] for s in range(K)])).to(dev)
-    xs[:, 2, 7, 3] = float("nan")  # instance 2: a NaN in its reference trajectory, every call
+    xs[1:, 2, 7, 3] = float("nan")  # instance 2: a NaN in its reference trajectory from the second call on (max_iter every time)
     a, b = (qrw_hip.Batch(B, n_steps=N) for _ in range(2))
     its = torch.zeros((K, B), dtype=torch.int32, device=dev)
     t0 = __import__("time").perf_counter()
@@ -451,7 +451,7 @@ def test_sequence_tail_longer_than_the_give_up_clock(synth_mod):
     el = __import__("time").perf_counter() - t0
     assert not b.mpc_sequence_timed_out()
     it = its.cpu().numpy()
-    assert (it[:, 2] == 4000).all() and (it > 0).all(), it[:3]
+    assert (it[1:, 2] == 4000).all() and (it > 0).all(), it[:3]
     o = out.cpu().numpy()
     healthy = [0, 1, 3, 4, 5]
     assert np.isfinite(o[:, healthy]).all()
