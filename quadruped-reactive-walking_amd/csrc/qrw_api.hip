@@ -677,6 +677,14 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_sweeps: no HIP device");
   const int rc = qrw::sweeps_selftest(max_err);
   if (rc != 0) return rc;
+  double derr = 0.0;
+  const int drc = qrw::dissect_selftest(&derr);  // the N = 32 path: two-half factorisation with fill, root, both sweeps
+  if (drc != 0) {
+    char msg[200];
+    snprintf(msg, sizeof(msg), "qrw_selftest_sweeps: dissected N = 32 solve differs from the dense host solve (rc %d, relative error %.3g)", drc, derr);
+    return fail(3, msg);
+  }
+  if (max_err && derr > *max_err) *max_err = derr;
   KatResult kat;
   const int krc = mpc_known_answer_check(&kat);  // the whole solve, not only its sweeps
   if (krc != 0) {

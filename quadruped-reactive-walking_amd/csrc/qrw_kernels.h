@@ -112,6 +112,7 @@ int wbc_launch(const WbcArgs& a, hipStream_t stream);
 
 namespace qrw {
 int sweeps_selftest(double* max_err);
+int dissect_selftest(double* max_err);  // N = 32 dissected factorisation + solve against a dense host solve
 
 // ---- planners (planner_kernel.hip)
 enum PlannerMode { kPlanInit = 1, kPlanGait = 2, kPlanFootsteps = 4, kPlanTraj = 8, kPlanState = 16, kPlanOutputs = 32 };
