@@ -491,6 +491,77 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
   }
 }
 
+// ---- PRE: round-robin time slicing of one call's solves inside one launch (qrw_mpc_solve at N > 16, batch > resident slots).
+// A launch's workgroups are started in index order on the 512 resident slots (two-wavefront instances) and each runs to the
+// end of its solve, 150..4000 ADMM iterations that nobody can predict well enough (3.5 % of the N = 32 mixed-gait solves
+// hit max_iter, never the same instances; profiles/r3_lpt_sim_n32.txt): whatever the order, some long solves start in the
+// last round and the launch ends 1.26-1.29 x later than work / slots.  Here a workgroup runs AT MOST `pre_chunk`
+// iterations (cut at a multiple of 200, where OSQP's adaptive-rho test sits), then parks the instance -- the ADMM loop
+// variables go into the state slots the warm start uses, bit for bit -- and queues it; the grid has B * pre_cmax
+// workgroups, the first B take the instances directly, every later one takes the oldest parked instance from ONE FIFO
+// (round robin: all solves advance together, so when the slots outnumber the unfinished solves those are the genuinely long
+// ones, near their end).  Simulated on recorded counts: 1.10 x instead of 1.28 x.  A resumed solve re-assembles and
+// re-equilibrates (deterministic: same inputs), reloads the loop variables, re-factors for the rho it was parked with and
+// goes on with iteration it0 + 1: the same arithmetic as the uninterrupted solve, so iteration counts, status and results
+// are identical (the parity tests run through this path).
+//   pre_ctr words: 0 head (next slot to take), 16 tail (next slot to fill), 32 finished instances, 33 error, 34 progress
+constexpr int kPreHead = 0, kPreTail = 16, kPreDone = 32, kPreErr = 33, kPreProgress = 34;
+static_assert(kPreProgress < kPreCtrWords, "pre_ctr too small");
+template <int NW>
+__device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
+  int task = -1;
+  if (tid == 0) {
+    const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot < (unsigned)a.pre_cap) {
+      SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
+      const int* q = a.pre_queue + slot;
+      for (;;) {
+        task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (task >= 0) break;
+        if (q_load(&a.pre_ctr[kPreDone]) >= (unsigned)a.B) break;  // every instance has finished: nothing will be parked any more
+        if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;               // somebody gave up already: do not wait another 2 s each
+        __builtin_amdgcn_s_sleep(32);
+        if (clock.expired()) {  // 2 s without any chunk of the launch ending: give up, loudly
+          __hip_atomic_store(&a.pre_ctr[kPreErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      if (task >= 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  }
+  if constexpr (NW == 1) {
+    task = __builtin_amdgcn_readfirstlane(task);
+  } else {
+    int* si = reinterpret_cast<int*>(sh);
+    if (tid == 0) si[0] = task;
+    __syncthreads();
+    task = si[0];
+    __syncthreads();
+  }
+  return task;
+}
+// end of a chunk: parked (queue the instance) or finished (count it)
+template <int NW>
+__device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool parked, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of the instance's state have left
+  if constexpr (NW > 1) __syncthreads();
+  if (tid == 0) {
+    if (parked) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreTail], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < (unsigned)a.pre_cap) __hip_atomic_store(&a.pre_queue[slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(&a.pre_ctr[kPreErr], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_fetch_add(&a.pre_ctr[kPreDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_fetch_add(&a.pre_ctr[kPreProgress], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // FULL: N == 16 * NW, every lane owns a live horizon step (the masks on `act` fold away)
 // SEQ = false: one workgroup solves one instance's one MPC call (qrw_mpc_solve).
 // SEQ = true:  K * B workgroups (one task each) work through K consecutive calls of every instance (qrw_mpc_solve_sequence): tasks
@@ -500,8 +571,10 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 //   resident one ends, exactly as in the one-call launch.  (A first version kept persistent workgroups in a task loop; with
 //   the loop around it the body was compiled with 42-140 spilled SGPRs and 364 B of scratch per lane and ran 5 % slower per
 //   ADMM iteration.  Without the loop the two forms compile alike.)
-template <int NW, bool FULL, bool SEQ>
+// PRE = true:  B * pre_cmax workgroups time-slice ONE call's solves (see pre_next_task above).
+template <int NW, bool FULL, bool SEQ, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
+  static_assert(!(SEQ && PRE), "one queueing mode at a time");
   // N = 32, OPTIONAL (-DQRW_N32_DISSECT=1): the state system dissected around step 16 so that both wavefronts sweep their own
   // half (dissect.h).  Parity-green with identical iteration counts, but measured SLOWER than the twisted form below (60 k
   // against 75 k control steps/s at batch 4096, DESIGN.md 6b "round 3": the sweeps' 2.2 k clocks saved per iteration are
@@ -528,9 +601,23 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #endif
     seq_s = task / a.B;
     b = task - seq_s * a.B;
+  } else if constexpr (PRE) {
+    if ((int)blockIdx.x < a.B) {
+      b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    } else {
+      b = pre_next_task<NW>(a, &L.sBal[0], tid);
+      if (b < 0) return;  // every instance has finished (or the queue gave up: the error word is set)
+    }
   } else {
     b = a.order ? a.order[blockIdx.x] : blockIdx.x;
   }
+  // PRE: iteration this instance was parked at by an earlier chunk of THIS launch (0: a fresh solve; a workgroup that takes
+  // its instance by index starts the solve whatever an aborted launch may have left behind)
+  int it_resume = 0;
+  if constexpr (PRE) {
+    if ((int)blockIdx.x >= a.B) it_resume = a.pause_it[b];
+  }
+  const bool resumed = PRE && it_resume > 0;
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
   const bool act = FULL ? true : (k < N);
@@ -581,6 +668,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   double* st = a.st + (size_t)b * kMpcStItems * T;
   const int num_iter = (a.num_iter ? a.num_iter[b] : a.num_iter_scalar) + seq_s;
   const bool first = (num_iter == 0);
+  bool parked = false;  // PRE: this chunk ended before the solve did
 #define ST(item) st[(item)*T + tid]
 
   if (!first && !a.flags[b]) {  // reference would dereference an un-setup OSQP workspace
@@ -623,13 +711,15 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   double sfl[3];      // S_gait entries of (k, foot j) (MPC.cpp:665-681)
   double rho;
   double xX[3], xF[3], zD[3], zC[5], yD[3], yS[3], yC[5];
-  if (first) {
+  if (first && !resumed) {
     rho = 0.1;
 #pragma unroll
     for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = sfl[t] = 0.0;
 #pragma unroll
     for (int c = 0; c < 5; c++) zC[c] = yC[c] = 0.0;
   } else {
+    // (PRE, resumed: the same slots hold the ADMM loop variables of the parked solve -- xh in x, theta / eta in y, zeta in
+    // z -- and B / S as the parked chunk used them, also for a first call)
     rho = ST(kStRho);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
@@ -826,9 +916,13 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   // (1-alpha) zeta + eta, Omega l, Omega u) and eta+ = (alpha Omega A_hat x~ + (1-alpha) zeta + eta) - zeta+.
   double xhX[3], xhF[3], thD[3], etS[3], zeC[5], etC[5];
 #pragma unroll
-  for (int t = 0; t < 3; t++) { xhX[t] = Dx0[t] * xX[t]; xhF[t] = Df0[t] * xF[t]; etS[t] = Es[t] * yS[t]; }
+  for (int t = 0; t < 3; t++) {
+    xhX[t] = resumed ? xX[t] : Dx0[t] * xX[t];
+    xhF[t] = resumed ? xF[t] : Df0[t] * xF[t];
+    etS[t] = resumed ? yS[t] : Es[t] * yS[t];
+  }
 #pragma unroll
-  for (int c = 0; c < 5; c++) etC[c] = Ec[c] * yC[c];
+  for (int c = 0; c < 5; c++) etC[c] = resumed ? yC[c] : Ec[c] * yC[c];
   // per-lane constants of the current rho (set with every factorisation)
   double aOD[3], kD[3], zeU[3], aOS[3], aOC[5], sDx2[3], sDf2[3], lz4 = 0.0;
 #pragma unroll
@@ -865,20 +959,29 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const int max_iter = 4000;
   rho = fmin(fmax(rho, kRhoMin), kRhoMax);
   {  // loop variables from the warm start (OSQP's scaled x, z, y of the previous solve, used as they are)
-    rho_used = rho;
-    const double rho_eq0 = kRhoEqOverIneq * rho;
+    // (PRE, resumed: rho is the value the solve was parked with, possibly just adapted; the loop constants and zeta_u belong
+    // to the rho of the parked factorisation, kept in the cost-scale slot: the factor block below re-bases them exactly as
+    // the uninterrupted solve does at this iteration)
+    rho_used = resumed ? ST(kStC) : rho;
+    const double rho_eq0 = kRhoEqOverIneq * rho_used;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       zeU[t] = (rho_eq0 * Ed[t] * Ed[t]) * uD0[t];
       const double eta = Ed[t] * yD[t], ze0 = rho_eq0 * Ed[t] * zD[t];
       // first iteration: zbar is the warm start, not yet the bound: the right-hand side takes zeta0 - eta0, and eta is
       // shifted so that the relaxed update sees (1-alpha) zeta0 where later iterations see (1-alpha) zeta_u
-      wD[t] = act ? ze0 - eta : 0.0;
-      thD[t] = (eta + (1.0 - alpha) * (ze0 - zeU[t])) - zeU[t];
+      const double th0 = (eta + (1.0 - alpha) * (ze0 - zeU[t])) - zeU[t];
+      thD[t] = resumed ? yD[t] : th0;
+      wD[t] = act ? (resumed ? -yD[t] : ze0 - eta) : 0.0;
     }
 #pragma unroll
-    for (int c = 0; c < 5; c++) zeC[c] = rho * Ec[c] * zC[c];
+    for (int c = 0; c < 5; c++) zeC[c] = resumed ? zC[c] : rho * Ec[c] * zC[c];
+    if (resumed) rho_updates = a.rho_updates[b];
   }
+  // PRE: a solve parked with an unchanged rho resumes with the loop constants it had: the re-basing of theta / wD in the
+  // factor block must then be the identity.  As written it is not: `zu_new - zeU` is contracted into one fma, which returns
+  // the rounding error of the product instead of 0 (harmless in a fresh solve, where the uninterrupted run does the same)
+  bool same_rho_resume = resumed && (rho == rho_used);
   // values only the factorisation, the termination check and the exit read: parked in accumulation registers, so that
   // they do not compete with the loop's own values for the architectural ones
   AccD pEd[3], pEs[3], pEc[5], pIDx[3], pIDf[3], pUD0[3], pWX[3], pCs;
@@ -899,7 +1002,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const double cs = pCs.get();
 
   PH(8);
-  for (iter = 1; iter <= max_iter; iter++) {
+  for (iter = it_resume + 1; iter <= max_iter; iter++) {
     PH(9);
     if (need_factor) {
       need_factor = false;
@@ -914,7 +1017,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) {
           const double zu_new = omD[t] * uD0[t];
-          const double shift = zu_new - zeU[t];
+          double shift = zu_new - zeU[t];
+          if constexpr (PRE) shift = same_rho_resume ? 0.0 : shift;
           thD[t] -= shift;
           wD[t] = act ? wD[t] + shift : 0.0;
           zeU[t] = zu_new;
@@ -929,6 +1033,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           aOC[c] = alpha * omC[c];
         }
         rho_used = rho;
+        same_rho_resume = false;
         lz4 = omC[4] * -25.0;  // f_z <= 25 (MPC.cpp:293-300); the other cone rows have l = -inf
       }
       double omL[3], omA[3], Kinv[6][6];
@@ -1279,8 +1384,14 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           rho_updates++;
           need_factor = true;
         }
+        if constexpr (PRE) {  // end of this workgroup's time slice: park the solve here (after the rho test, before iteration iter + 1)
+          if (iter - it_resume >= a.pre_chunk && iter < max_iter) parked = true;
+        }
       }
       PH(7);
+      if constexpr (PRE) {
+        if (parked) break;
+      }
     }
   }
   PH(7);
@@ -1288,7 +1399,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
 #endif
   if (iter > max_iter) iter = max_iter;
-  if (status == kStatusUnsolved) {
+  if (status == kStatusUnsolved && !parked) {
     // max_iter reached (4000 % 25 == 0: the residuals of the last iterate were just computed): OSQP re-checks with
     // 10x tolerances, check_termination(work, 1)
     const bool pok = pri_res < 10.0 * eps_abs + 10.0 * eps_rel * last_np;
@@ -1300,7 +1411,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   {
   QRW_UNPARK()
   const bool has_sol = (status != kStatusNonCvx);
-  if (act) {
+  if (act && !parked) {
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const int i = 3 * j + t;
@@ -1310,16 +1421,19 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       outp[(12 + i) * N + k] = sf;    // MPC.cpp:574
     }
   }
-  // back to OSQP's scaled iterates for the persistent state
+  // back to OSQP's scaled iterates for the persistent state (PRE, parked: the loop variables as they are, bit for bit)
 #pragma unroll
   for (int t = 0; t < 3; t++) {
-    xX[t] = xhX[t] * iDx[t]; xF[t] = xhF[t] * iDf[t];
+    xX[t] = parked ? xhX[t] : xhX[t] * iDx[t]; xF[t] = parked ? xhF[t] : xhF[t] * iDf[t];
     zD[t] = Ed[t] * uD0[t];
-    yD[t] = (thD[t] + zeU[t]) * (1.0 / Ed[t]);
-    yS[t] = etS[t] * (1.0 / Es[t]);
+    yD[t] = parked ? thD[t] : (thD[t] + zeU[t]) * (1.0 / Ed[t]);
+    yS[t] = parked ? etS[t] : etS[t] * (1.0 / Es[t]);
   }
 #pragma unroll
-  for (int c = 0; c < 5; c++) { zC[c] = zeC[c] * (1.0 / (rho_used * Ec[c])); yC[c] = etC[c] * (1.0 / Ec[c]); }
+  for (int c = 0; c < 5; c++) {
+    zC[c] = parked ? zeC[c] : zeC[c] * (1.0 / (rho_used * Ec[c]));
+    yC[c] = parked ? etC[c] : etC[c] * (1.0 / Ec[c]);
+  }
   if (!has_sol) {  // store_solution(): cold start after a failed solve
 #pragma unroll
     for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = 0.0;
@@ -1327,7 +1441,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     for (int c = 0; c < 5; c++) zC[c] = yC[c] = 0.0;
   }
   ST(kStRho) = rho;
-  ST(kStC) = cs;
+  ST(kStC) = parked ? rho_used : cs;  // (parked: the rho of the factorisation the loop variables belong to)
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     ST(kStXX + t) = xX[t]; ST(kStXF + t) = xF[t]; ST(kStZD + t) = zD[t];
@@ -1338,7 +1452,13 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
 #pragma unroll
   for (int c = 0; c < 5; c++) { ST(kStZC + c) = zC[c]; ST(kStYC + c) = yC[c]; ST(kStEC + c) = Ec[c]; }
-  if (tid == 0) {
+  if (PRE && parked) {
+    if (tid == 0) {
+      a.pause_it[b] = iter;
+      a.rho_updates[b] = rho_updates;
+    }
+  } else if (tid == 0) {
+    if constexpr (PRE) a.pause_it[b] = 0;
     a.flags[b] = 1;
     a.iters[b] = iter;
     a.status[b] = status;
@@ -1357,6 +1477,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   }  // set up
   if constexpr (SEQ) seq_finish_task<NW>(a, b, seq_s, tid);
+  if constexpr (PRE) pre_end_chunk<NW>(a, b, parked, tid);
   }
 #undef QRW_UNPARK
 #undef ST
@@ -1462,6 +1583,15 @@ bool mpc_build_is_timing_experiment() {
 #else
   return false;
 #endif
+}
+
+// preemptive launch (N > 16 only): B * pre_cmax workgroups, the caller has reset pre_queue (-1) and pre_ctr (0) on the stream
+int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream) {
+  if (a.N <= 16 || a.N > kMpcMaxN || !a.pre_queue || !a.pre_ctr || !a.pause_it || a.pre_chunk < 200 || a.pre_cmax < 1) return -1;
+  const unsigned blocks = (unsigned)a.B * (unsigned)a.pre_cmax;
+  if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream) {

@@ -52,6 +52,11 @@ struct qrw_handle_s {
   int* seq_hot = nullptr;
   int* seq_first = nullptr;
   int seq_groups = 0;
+  // preemptive launch of qrw_mpc_solve (N > 16, more instances than resident slots): FIFO of parked solves, counters
+  int* pre_queue = nullptr;
+  unsigned* pre_ctr = nullptr;
+  int* pause_it = nullptr;
+  int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0;
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -252,6 +257,24 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->mpc_pri, B * sizeof(double));
   ALLOC(h->mpc_dua, B * sizeof(double));
   ALLOC(h->mpc_prof, B * 10 * sizeof(double));
+  if (N > 16) {
+    // round-robin time slicing of the solves of one call (mpc_kernel.hip, PRE): slices of QRW_PREEMPT_CHUNK iterations
+    // (default 600, rounded up to a multiple of 200; 0 switches it off), used when the batch exceeds the resident slots
+    const char* ce = getenv("QRW_PREEMPT_CHUNK");
+    int chunk = ce ? atoi(ce) : 600;
+    if (chunk > 0) {
+      chunk = ((chunk + 199) / 200) * 200;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { qrw_destroy(h); return fail(-10, "hipGetDeviceProperties"); }
+      h->pre_chunk = chunk;
+      h->pre_cmax = (4000 + chunk - 1) / chunk;
+      h->pre_min_batch = 2 * prop.multiProcessorCount;  // two two-wavefront instances per compute unit are resident
+      if (const char* mb = getenv("QRW_PREEMPT_MIN_BATCH")) h->pre_min_batch = atoi(mb);  // tests: slice small batches too
+      ALLOC(h->pause_it, B * sizeof(int));
+      ALLOC(h->pre_ctr, qrw::kPreCtrWords * sizeof(unsigned));
+      ALLOC(h->pre_queue, B * (size_t)(h->pre_cmax > 1 ? h->pre_cmax - 1 : 1) * sizeof(int));
+    }
+  }
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
   ALLOC(h->wbc_iters, B * sizeof(int));
   ALLOC(h->wbc_status, B * sizeof(int));
@@ -276,6 +299,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->mpc_dua); hipFree(h->mpc_prof); hipFree(h->wbc_st); hipFree(h->wbc_iters); hipFree(h->wbc_status);
   hipFree(h->plan_st); hipFree(h->ctrl_st);
   hipFree(h->seq_queue); hipFree(h->seq_ctr); hipFree(h->seq_hot); hipFree(h->seq_first);
+  hipFree(h->pre_queue); hipFree(h->pre_ctr); hipFree(h->pause_it);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -300,7 +324,15 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   a.rho_updates = h->mpc_rho_updates;
   a.prof = h->mpc_prof;
   a.order = h->mpc_have_order ? h->mpc_order : nullptr;
-  if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  if (h->pre_chunk > 0 && h->cfg.batch > h->pre_min_batch && h->pre_cmax > 1) {
+    // more instances than resident slots at N > 16: the solves are time-sliced round robin inside the launch (same results)
+    a.pre_chunk = h->pre_chunk; a.pre_cmax = h->pre_cmax; a.pre_cap = h->cfg.batch * (h->pre_cmax - 1);
+    a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
+    HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
+    HIP_OK(hipMemsetAsync(h->pre_ctr, 0, qrw::kPreCtrWords * sizeof(unsigned), (hipStream_t)stream), "qrw_mpc_solve: counter reset");
+    if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0)
+      return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  } else if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
   static const int order_min = getenv("QRW_ORDER_MIN") ? atoi(getenv("QRW_ORDER_MIN")) : 1024;  // experiments only
   if (h->cfg.batch > order_min) {
@@ -436,6 +468,12 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
   HIP_OK(hipDeviceSynchronize(), "sync");
+  if (h->pre_ctr) {  // a time-sliced launch whose queue gave up (never expected) left solves unfinished: say so, loudly
+    unsigned c[qrw::kPreCtrWords];
+    HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "D2H pre_ctr");
+    if (c[33] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
+                                     "or overran its queue; results of that call are incomplete");
+  }
   if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
   if (h_status) HIP_OK(hipMemcpy(h_status, h->mpc_status, B * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
   if (h_rho) HIP_OK(hipMemcpy(h_rho, h->mpc_rho, B * sizeof(double), hipMemcpyDeviceToHost), "D2H rho");

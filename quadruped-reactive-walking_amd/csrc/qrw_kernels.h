@@ -65,7 +65,16 @@ struct MpcArgs {
   int* seq_first;    // [B] call-0 tasks dealt by workgroup index
   int seq_groups;    // workgroups resident at a time = call-0 tasks dealt by index
   int* seq_iters;    // optional [seq_K][B]
+  // preemptive launch (mpc_preemptive_launch): round-robin time slices of pre_chunk iterations, parked solves in one FIFO
+  int pre_chunk;      // iterations per time slice (cut at the next multiple of 200)
+  int pre_cmax;       // most slices one solve can need = workgroups per instance in the grid
+  int pre_cap;        // slots in pre_queue = B * (pre_cmax - 1)
+  int* pre_queue;     // [pre_cap] parked instances in FIFO order, -1 = not filled yet
+  unsigned* pre_ctr;  // [kPreCtrWords] head / tail / finished / error / progress (mpc_kernel.hip)
+  int* pause_it;      // [B] iteration a solve was parked at, 0 = not parked
 };
+constexpr int kPreCtrWords = 48;
+int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
 bool mpc_build_is_timing_experiment();

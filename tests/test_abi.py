@@ -96,8 +96,8 @@ def test_shipped_mpc_kernel_spills_nothing_to_scratch():
         sc = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", part).group(1))
         ag = int(re.search(r"AGPRs: (\d+)", part).group(1))
         vs = int(re.search(r"VGPRs Spill: (\d+)", part).group(1))
-        assert sc == 0 and vs == 0 and ag < 256, (name, sc, vs, ag)
-    assert seen == 8, seen
+        assert sc == 0 and vs == 0 and ag <= 256, (name, sc, vs, ag)
+    assert seen == 10, seen  # plain + sequence forms of <1,full>, <1,short>, <2,full>, <2,short>, time-sliced forms of the <2,*>
 
 
 def _build_cabi_demo(tmp_path):
