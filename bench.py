@@ -348,6 +348,9 @@ def main():
                 xref=xref, fsteps=fsteps, q=q, dq=dq, contacts=contacts, pgoals=pg, vgoals=vg, agoals=ag))
             out["closed_loop_sequence"] = closed_loop_sequence(B, N, N_gait, gaits, dev, W, K)
             out["secondary_ratio_1_10"] = device_resident_loop(sb, B, N, N_gait, dev)
+            if B % 2 == 0:  # the same loop with the fleet as two stream groups (Controller_batch(groups=2), opt-in)
+                out["secondary_ratio_1_10_two_groups"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2)
+                out["secondary_ratio_1_10_two_groups_free"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2, free_running=True)
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
         if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
             # the metric reads "batch {1, 256, 4096}" and BASELINE lists configs 2 and 4: every single-GPU figure in this ONE line
@@ -708,12 +711,15 @@ def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
                     "%d timed calls after %d warm-up calls, inputs replayed from HBM" % (K, W)}
 
 
-def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=32):
+def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=32, groups=1, free_running=False):
     """Secondary figure: the reference's own 1:10 MPC:WBC ratio, whole Controller.compute iterations
     (scripts/Controller.py:200-326) on the device — updateState, the four planners, one MPC solve every k_mpc
     iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM.
     multiprocessing=True: the reference's asynchronous MPC mode (scripts/MPC_Wrapper.py:150-298) as two
-    compute-unit-masked streams.  Reports the free-running rate and the iteration latency when paced at dt_wbc = 2 ms."""
+    compute-unit-masked streams.  Reports the free-running rate and the iteration latency when paced at dt_wbc = 2 ms.
+    groups = 2: the fleet as two stream groups (Controller_groups), results identical; free_running = True additionally
+    keeps the stand-in for the robots (perfect tracking of the PD targets) per group on the group's stream, so that the
+    groups are never joined and one group's straggling solves run beside the other group's iterations."""
     import torch
 
     from Controller import Controller_batch
@@ -722,7 +728,8 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     # the masked streams synchronise with the legacy default stream: keep the caller's own work off it
     with torch.cuda.stream(torch.cuda.Stream(dev)):
         ctl = Controller_batch(B, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=k_mpc, T_gait=0.02 * N, T_mpc=0.02 * N,
-                               N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing, loop_cus=loop_cus)
+                               N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing, loop_cus=loop_cus,
+                               groups=groups)
         # half the joystick range of the headline workload: at up to 1.5 m/s a sixth of the instances run into the
         # controller's joint-limit / torque security stop within 100 iterations (reference behaviour), which would
         # make the figure depend on how many robots have already been stopped
@@ -736,9 +743,24 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
         vs = torch.zeros((B, 12), dtype=torch.float64, device=dev)
 
         def it():
+            if free_running and groups > 1:
+                for g in range(groups):
+                    sl = ctl.slice_of(g)
+                    with torch.cuda.stream(ctl.stream_of(g)):
+                        r = ctl.compute_group(g, vref[sl], qf[sl], vf[sl], rpy[sl], vs[sl])
+                        qf[sl, 7:].copy_(r.q_des)
+                        vf[sl, 6:].copy_(r.v_des)
+                return
             r = ctl.compute(vref, qf, vf, rpy, vs)
             qf[:, 7:].copy_(r.q_des)  # perfect tracking of the PD targets stands in for the robot
             vf[:, 6:].copy_(r.v_des)
+
+        def wait_iteration():
+            if free_running and groups > 1:
+                for g in range(groups):
+                    ctl.stream_of(g).synchronize()
+            else:
+                torch.cuda.current_stream().synchronize()
 
         for k in range(2 * k_mpc):
             it()
@@ -756,13 +778,16 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
             nxt = max(nxt + 0.002, time.perf_counter())
             a = time.perf_counter()
             it()
-            torch.cuda.current_stream().synchronize()
+            wait_iteration()
             lat.append(time.perf_counter() - a)
         bad = int((ctl.error_flag != 0).sum().item())
         ctl.stop_parallel_loop()
     lat = 1e3 * np.array(lat)
     what = ("whole Controller.compute iterations (state update, planners, glue, WBC every iteration, MPC every %d-th), "
             "device-resident, batch %d, reference velocities = half the headline workload's" % (k_mpc, B))
+    if groups > 1:
+        what += "; fleet as %d stream groups (%s)" % (groups, "never joined: the robots' stand-in runs per group" if free_running
+                                                      else "joined on the caller's stream every iteration")
     if multiprocessing:
         what += ("; asynchronous MPC mode: solves on their own stream (224 compute units), the control loop on a stream "
                  "with the other 32, a result adopted when its event has completed")

@@ -20,9 +20,22 @@ class Result:
 
 
 class Controller_batch:
+    def __new__(cls, batch, *args, groups=None, **kwargs):
+        # groups > 1: the fleet as independent stream groups, see Controller_groups (opt-in: measured below)
+        if cls is Controller_batch and (groups if groups is not None else 1) > 1:
+            return super().__new__(Controller_groups)
+        return super().__new__(cls)
+
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
-                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True):
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
+                 _out_views=None):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
+
+        groups: None / 1 = one handle; G > 1 = the fleet as G stream groups (Controller_groups).  Not the default: in the 1:10
+        loop at batch 4096 two groups joined on the caller's stream every iteration run at 9.6 M iterations/s against 10.7 M
+        for the single handle (twice the launches, one join per iteration), never joined (compute_group on the groups' own
+        streams) at 10.95 M; the paced worst-case latency (5.6 ms, the iteration that carries the solve) is the same in all
+        three -- only the asynchronous mode (0.35 ms) removes it (bench.py, secondary_ratio_1_10*).
 
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
         on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
@@ -55,6 +68,15 @@ class Controller_batch:
         self.x_f_mpc = self._mpc_default
         self.fused = bool(fused)  # two launches per iteration (+ the solve) instead of five; same arithmetic
         self._pre = self._post = None
+        if _out_views is not None:
+            # a stream group of a larger fleet: result / error flag are written straight into the fleet's tensors
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.dev)
+            B = self.B
+            if self.fused:
+                self._post = dict(tau_ff=mk(B, 12), qdes=mk(B, 19), vdes=mk(B, 18), f_with_delta=mk(B, 12), ddq_res=mk(B, 6),
+                                  feet=mk(B, 3, 3, 4), result=_out_views["result"], error_flag=_out_views["error_flag"])
+            else:
+                self._res = dict(result=_out_views["result"], error_flag=_out_views["error_flag"])
         self.multiprocessing = bool(multiprocessing)
         self.mpc_lag = mpc_lag
         if self.multiprocessing:
@@ -200,3 +222,83 @@ class Controller_batch:
 
     def stats(self):
         return dict(mpc=self._b.mpc_stats(), wbc=self._b.wbc_stats())
+
+
+class Controller_groups(Controller_batch):
+    """`Controller_batch(batch, ..., groups=G)`: the fleet as G independent stream groups, each a single-handle
+    Controller_batch of batch / G robots on its own stream (qrw_hip.StreamGroups' stream pool).
+
+    Why: one handle steps the whole fleet with one launch per kernel, and the MPC launch ends with its longest solve while
+    most of the chip is already idle; with two groups in flight one group's stragglers run beside the
+    other group's work.  The robots are independent, so every robot's results are those of the single handle, bit for bit
+    (tests/test_gpu_controller.py).
+
+    compute() keeps the single-handle contract: whole-fleet inputs in, whole-fleet Result out, valid on the caller's stream
+    (which is made to wait for every group: one join per iteration; measured slower than the single handle in the 1:10 loop,
+    see Controller_batch.__init__).  A caller whose own feedback is per robot as well can
+    skip the join and let the groups run free: `compute_group(g, ...)` with that group's slices `slice_of(g)` on the stream
+    `stream_of(g)` (what bench.py's 1:10 figure does)."""
+
+    def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
+                 _out_views=None):
+        import torch
+
+        G = int(groups) if groups is not None else 2
+        if G < 2 or int(batch) % G:
+            raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (batch, G))
+        self._torch = torch
+        self.B, self.G, self.Bs = int(batch), G, int(batch) // G
+        self.dev = torch.device("cuda:%d" % device)
+        self.k, self.k_mpc, self.h_ref, self.dt_wbc = 0, int(k_mpc), float(h_ref), float(dt_wbc)
+        self.n_steps = int(round(T_mpc / dt_mpc))
+        self.multiprocessing, self.fused = bool(multiprocessing), bool(fused)
+        self._fleet_result = torch.empty((self.B, 5, 12), dtype=torch.float64, device=self.dev)
+        self.error_flag = torch.zeros((self.B,), dtype=torch.int32, device=self.dev)
+        self.result = Result(self._fleet_result)
+        qi = np.broadcast_to(np.asarray(q_init, dtype=np.float64).reshape(-1, 12), (self.B, 12))
+        self._sl = [slice(g * self.Bs, (g + 1) * self.Bs) for g in range(G)]
+        for g in range(G):
+            if (device, g) not in qrw_hip.StreamGroups._streams:
+                qrw_hip.StreamGroups._streams[(device, g)] = torch.cuda.Stream(self.dev)
+        self.streams = [qrw_hip.StreamGroups._streams[(device, g)] for g in range(G)]
+        self.groups = []
+        for g, sl in enumerate(self._sl):
+            with torch.cuda.stream(self.streams[g]):
+                self.groups.append(Controller_batch(
+                    self.Bs, qi[sl], dt_wbc=dt_wbc, dt_mpc=dt_mpc, k_mpc=k_mpc, T_gait=T_gait, T_mpc=T_mpc, N_gait=N_gait,
+                    h_ref=h_ref, device=device, multiprocessing=multiprocessing, loop_cus=loop_cus, mpc_lag=mpc_lag, fused=fused,
+                    groups=1, _out_views=dict(result=self._fleet_result[sl], error_flag=self.error_flag[sl])))
+
+    def slice_of(self, g):
+        return self._sl[g]
+
+    def stream_of(self, g):
+        return self.streams[g]
+
+    def compute_group(self, g, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
+        """One control iteration of group g alone: arguments are that group's slices (contiguous, leading dimension
+        batch / groups), enqueued on the CURRENT stream -- call it under `torch.cuda.stream(ctl.stream_of(g))`."""
+        code = joystick_code[self._sl[g]] if self._torch.is_tensor(joystick_code) else joystick_code
+        return self.groups[g].compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, code)
+
+    def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
+        torch = self._torch
+        caller = torch.cuda.current_stream(self.dev)
+        for g, (sl, st) in enumerate(zip(self._sl, self.streams)):
+            st.wait_stream(caller)  # the inputs produced on the caller's stream are ready
+            with torch.cuda.stream(st):
+                self.compute_group(g, joy_v_ref[sl], q_filt[sl], v_filt[sl], rpy[sl], v_secu[sl], joystick_code)
+        for st in self.streams:
+            caller.wait_stream(st)
+        self.k += 1
+        return self.result
+
+    def stop_parallel_loop(self):
+        for c in self.groups:
+            c.stop_parallel_loop()
+        self.multiprocessing = False
+
+    def stats(self):
+        st = [c.stats() for c in self.groups]
+        return {k: {kk: np.concatenate([s_[k][kk] for s_ in st]) for kk in st[0][k]} for k in st[0]}

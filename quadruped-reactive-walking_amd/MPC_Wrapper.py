@@ -163,15 +163,32 @@ class MPC_Wrapper:
 class MPC_Wrapper_batch:
     """B instances, device-resident. solve_batch(k, xref (B,12,N+1), fsteps (B,N_gait,12)) runs one MPC
     iteration for every instance on the caller's stream; get_latest_result_batch() -> (B,24,N).
-    Before the first solve it returns the reference's default result (scripts/MPC_Wrapper.py:64-71)."""
+    Before the first solve it returns the reference's default result (scripts/MPC_Wrapper.py:64-71).
 
-    def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0):
+    groups (default 1; opt-in): the fleet as independent stream groups, each with its own handle
+    and stream (qrw_hip.StreamGroups' stream pool): a launch ends with its longest solve while most of the chip is idle,
+    and with two groups in flight one group's stragglers run beside the other group's next solve.  Same results, bit for
+    bit.  solve_batch then returns at once; get_latest_result_batch() makes the caller's stream wait for the groups."""
+
+    def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0, groups=None):
         import torch
 
         self._torch = torch
-        self.B, self.n_steps, self.N_gait = int(batch), int(n_steps), int(N_gait)
-        self._b = qrw_hip.Batch(self.B, n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt),
-                                T_gait=float(T_gait), device=device)
+        self.B, self.n_steps, self.N_gait, self.device = int(batch), int(n_steps), int(N_gait), int(device)
+        G = int(groups) if groups is not None else 1
+        if G < 1 or self.B % G:
+            raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (self.B, G))
+        self.G, self.Bs = G, self.B // G
+        dev = torch.device("cuda:%d" % device)
+        self._bs = [qrw_hip.Batch(self.Bs, n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt), T_gait=float(T_gait),
+                                  device=device) for _ in range(G)]
+        self._b = self._bs[0]
+        self._sl = [slice(g * self.Bs, (g + 1) * self.Bs) for g in range(G)]
+        if G > 1:
+            for g in range(G):
+                if (device, g) not in qrw_hip.StreamGroups._streams:
+                    qrw_hip.StreamGroups._streams[(device, g)] = torch.cuda.Stream(dev)
+            self._streams = [qrw_hip.StreamGroups._streams[(device, g)] for g in range(G)]
         first = np.zeros((self.B, 24, self.n_steps))
         if q_init is not None:
             q_init = np.asarray(q_init, dtype=np.float64).reshape(self.B, 19)
@@ -179,22 +196,53 @@ class MPC_Wrapper_batch:
             for b in range(self.B):
                 first[b, 3:6, 0] = quaternionToRPY(q_init[b, 3:7]).ravel()
         first[:, 12:, 0] = np.array([0.0, 0.0, 8.0] * 4)
-        self._result = torch.from_numpy(first).to("cuda:%d" % device)
+        self._result = torch.from_numpy(first).to(dev)
         self._out = None
+        self._in_flight = False
         self.not_first_iter = False
 
     def solve_batch(self, k, xref, fsteps):
-        self._out = self._b.mpc_solve(xref, fsteps, k, out=self._out)
+        torch = self._torch
+        if self.G == 1:
+            self._out = self._b.mpc_solve(xref, fsteps, k, out=self._out)
+            return 0
+        if self._out is None:
+            self._out = torch.empty((self.B, 24, self.n_steps), dtype=torch.float64, device=xref.device)
+        cur = torch.cuda.current_stream(self.device)
+        for eng, st, sl in zip(self._bs, self._streams, self._sl):
+            st.wait_stream(cur)  # inputs produced on the caller's stream are ready (and the previous result has been consumed)
+            with torch.cuda.stream(st):
+                eng.mpc_solve(xref[sl], fsteps[sl], k[sl] if isinstance(k, torch.Tensor) else k, out=self._out[sl])
+        self._in_flight = True
         return 0
+
+    def _join(self):
+        if self._in_flight:
+            cur = self._torch.cuda.current_stream(self.device)
+            for st in self._streams:
+                cur.wait_stream(st)
+            self._in_flight = False
 
     def replay_batch(self, k0, xref_log, fsteps_log, out=None):
         """Recompute `mpc_x_f` for logged planner outputs: xref_log (K,B,12,N+1), fsteps_log (K,B,N_gait,12) as
         `LoggerControl` records them (`planner_xref`, `planner_fsteps`, scripts/LoggerControl.py:61-65,142-143) ->
         (K,B,24,N) (`mpc_x_f`, :76,:152).  Same results as K calls of solve_batch(k0 + s, ...), but one launch ordered per
         instance only (qrw_mpc_solve_sequence); for inputs known beforehand, not for a closed loop.  The last call's
-        result becomes the latest result."""
-        res = self._b.mpc_solve_sequence(xref_log, fsteps_log, k0, out=out)
-        if self._b.mpc_sequence_timed_out():  # synchronises; calls that never ran are NaN in res
+        result becomes the latest result.  (A diagnostic for log replay; with groups the slices are replayed one after the
+        other.)"""
+        if self.G == 1:
+            res = self._b.mpc_solve_sequence(xref_log, fsteps_log, k0, out=out)
+            bad = self._b.mpc_sequence_timed_out()
+        else:
+            self._join()
+            torch = self._torch
+            K = int(xref_log.shape[0])
+            res = out if out is not None else torch.empty((K, self.B, 24, self.n_steps), dtype=torch.float64, device=xref_log.device)
+            bad = False
+            for eng, sl in zip(self._bs, self._sl):
+                res[:, sl] = eng.mpc_solve_sequence(xref_log[:, sl].contiguous(), fsteps_log[:, sl].contiguous(), k0)
+                bad = eng.mpc_sequence_timed_out() or bad
+        if bad:  # (synchronises) calls that never ran are NaN in res
             raise qrw_hip.QrwError("replay_batch: the sequence kernel's task queue gave up waiting (2 s without progress); "
                                    "calls that did not run are NaN in the result")
         self._out = res[-1]
@@ -202,10 +250,15 @@ class MPC_Wrapper_batch:
 
     def get_latest_result_batch(self):
         """scripts/MPC_Wrapper.py:106-126, synchronous branch: the first call returns the default forces."""
+        if self.G > 1:
+            self._join()
         if self.not_first_iter:
             return self._out if self._out is not None else self._result
         self.not_first_iter = True
         return self._result
 
     def stats(self):
-        return self._b.mpc_stats()
+        if self.G > 1:
+            self._join()
+        st = [b.mpc_stats() for b in self._bs]
+        return {k: np.concatenate([s_[k] for s_ in st]) for k in st[0]}

@@ -289,3 +289,63 @@ def test_control_pre_without_mpc_inputs_leaves_the_rest_unchanged():
         assert torch.equal(full["xref"][:, :, :2], lazy["xref"][:, :, :2])
         if k > 1:
             assert bool((lazy["fsteps"] == -7.0).all()) and bool((lazy["gait"] == -7.0).all()) and bool((lazy["xref"][:, :, 2:] == -7.0).all())
+
+
+@pytest.mark.parametrize("mode", ["sync", "async_lag2"])
+def test_stream_groups_controller_equals_the_single_handle(mode):
+    """Controller_batch(..., groups=2) (Controller_groups: the fleet as two independent stream groups, opt-in) against the
+    single handle: the robots are independent, so Result and error flag must be
+    equal bit for bit over a closed loop that crosses several MPC iterations -- through compute() (joined every iteration)
+    and through compute_group() on the groups' own streams (never joined).  Synchronous mode and the asynchronous MPC mode
+    with a deterministic adoption lag."""
+    import torch
+    from Controller import Controller_batch, Controller_groups
+
+    B, iters = 64, 27
+    kw = dict(multiprocessing=(mode != "sync"), mpc_lag=(None if mode == "sync" else 2))
+    rng = np.random.default_rng(5)
+    qi = Q_INIT + rng.uniform(-0.03, 0.03, (B, 12))
+    vref = _t(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0]))
+
+    def run(ctl, free):
+        qf = torch.zeros((B, 19), dtype=torch.float64, device="cuda")
+        qf[:, 2], qf[:, 6] = 0.2229, 1.0
+        qf[:, 7:] = _t(qi)
+        vf = torch.zeros((B, 18), dtype=torch.float64, device="cuda")
+        vf[:, :6] = vref
+        rpy = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        vs = torch.zeros((B, 12), dtype=torch.float64, device="cuda")
+        hist = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for it in range(iters):
+                if free:
+                    for g in range(ctl.G):
+                        sl = ctl.slice_of(g)
+                        with torch.cuda.stream(ctl.stream_of(g)):
+                            r = ctl.compute_group(g, vref[sl], qf[sl], vf[sl], rpy[sl], vs[sl])
+                            qf[sl, 7:].copy_(r.q_des)
+                            vf[sl, 6:].copy_(r.v_des)
+                    for g in range(ctl.G):
+                        ctl.stream_of(g).synchronize()
+                    hist.append(ctl._fleet_result.clone())
+                else:
+                    r = ctl.compute(vref, qf, vf, rpy, vs)
+                    qf[:, 7:].copy_(r.q_des)
+                    vf[:, 6:].copy_(r.v_des)
+                    torch.cuda.current_stream().synchronize()
+                    hist.append(torch.stack([r.P, r.D, r.q_des, r.v_des, r.tau_ff], 1).clone())
+            flag = ctl.error_flag.clone()
+        ctl.stop_parallel_loop()
+        return torch.stack(hist), flag
+
+    one = Controller_batch(B, qi, groups=1, **kw)
+    assert not isinstance(one, Controller_groups)
+    ref, ref_flag = run(one, False)
+    two = Controller_batch(B, qi, groups=2, **kw)
+    assert isinstance(two, Controller_groups) and not isinstance(Controller_batch(8, Q_INIT), Controller_groups)
+    got, flag = run(two, False)
+    assert torch.equal(got, ref) and torch.equal(flag, ref_flag)
+    got, flag = run(Controller_batch(B, qi, groups=2, **kw), True)
+    assert torch.equal(got, ref) and torch.equal(flag, ref_flag)
+    with pytest.raises(Exception):
+        Controller_batch(7, Q_INIT, groups=2)

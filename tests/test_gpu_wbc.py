@@ -322,3 +322,29 @@ def test_stream_groups_give_the_single_handle_results(synth_mod):
     grp.close()
     with pytest.raises(qrw_hip.QrwError):
         qrw_hip.StreamGroups(7, groups=2)
+
+
+def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
+    """MPC_Wrapper_batch(..., groups=2) (two handles on two streams, opt-in) returns what the
+    single handle returns, bit for bit, for int and per-instance iteration arguments, incl. the default result before the
+    first solve and replay_batch."""
+    import torch
+
+    import MPC_Wrapper
+
+    B, N, K = 2052, 16, 4
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=99200)
+    a = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=1)
+    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=2)
+    assert a.G == 1 and b.G == 2 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 8).G == 1
+    assert torch.equal(a.get_latest_result_batch(), b.get_latest_result_batch())  # the default forces
+    for s in range(K):
+        d = sb.step(s)
+        x, f = torch.from_numpy(d["xref"]).cuda(), torch.from_numpy(d["fsteps"]).cuda()
+        k = s if s % 2 == 0 else torch.full((B,), s, dtype=torch.int32, device="cuda")
+        a.solve_batch(k, x, f)
+        b.solve_batch(k, x, f)
+        assert torch.equal(a.get_latest_result_batch(), b.get_latest_result_batch()), s
+        torch.cuda.synchronize()
+    sa, sb_ = a.stats(), b.stats()
+    assert np.array_equal(sa["iters"], sb_["iters"]) and np.array_equal(sa["status"], sb_["status"])
