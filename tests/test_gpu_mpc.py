@@ -547,3 +547,38 @@ def test_time_sliced_launch_matches_the_oracle(oracle_mod, synth_mod, monkeypatc
         g = eng.mpc_stats()
         assert np.array_equal(g["iters"], it) and np.array_equal(g["status"], st), s
         assert rel_err(out[:, :12], r[:, :12]) < RTOL and rel_err(out[:, 12:], r[:, 12:]) < RTOL, s
+
+
+def test_twostance_closed_loop_grows_at_the_monodromy_rate_on_the_hip_path():
+    """The red reference-held pin (scripts/test_mpc.py:162-190), HIP side of tests/test_oracle_mpc.py::
+    test_twostance_monodromy_explains_the_red_known_answer: from a start 1 % of the way to the reference's non-centred
+    state the HIP path's closed loop (state := first predicted state) deviates from the reference at the rate the one-period
+    map of the unconstrained MPC law predicts for the weights of src/MPC.cpp:330 (spectral radius 1.20 per gait period,
+    tests/monodromy.py: independent assembly + dense KKT solves) -- the scenario is unstable for the QP as written, on
+    the CPU oracle and on the GPU alike."""
+    import monodromy as mono
+    import qrw_hip
+    import trot_kat
+
+    N = trot_kat.N
+    rho = mono.spectral_radius(mono.W_330)
+    centre = np.zeros(12)
+    centre[2] = trot_kat.H_REF
+    start = centre + 0.01 * (trot_kat.NOT_CENTERED - centre)
+    eng = qrw_hip.Batch(1, n_steps=N, N_gait=trot_kat.N_GAIT)
+    err = []
+
+    def solve(i, xref, fsteps):
+        r = eng.mpc_solve_host(xref[None], fsteps[None], i)[0]
+        assert eng.mpc_stats()["status"][0] == 1
+        err.append(np.abs(r[:12, 0] - xref[:, 1]).max())
+        return r
+
+    old = trot_kat.NOT_CENTERED
+    trot_kat.NOT_CENTERED = start
+    try:
+        trot_kat.run_twostance(solve, 161, centered=False)
+    finally:
+        trot_kat.NOT_CENTERED = old
+    growth = err[160] / err[96]
+    assert 1.17 < rho < 1.23 and 0.85 * rho ** 4 < growth < 1.15 * rho ** 4, (rho, growth)
