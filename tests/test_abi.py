@@ -62,31 +62,37 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in src and "qrw_oracle" not in src and "osqp_restate" not in src, f
 
 
-def test_shipped_mpc_kernel_spills_nothing_to_scratch():
+def test_shipped_mpc_kernel_spills_nothing_to_scratch(tmp_path):
     """The MPC kernel lives at the edge of the register file (256 VGPRs + ~254 AGPRs).  The one build on record that
     computed wrong results was one in which the allocator ran out of accumulation registers and went to
-    scratch; the shipped flags must leave the N = 16 instantiation with no scratch and with AGPRs to spare."""
+    scratch while inline-asm-pinned values (AccD) were live; the shipped flags must leave EVERY instantiation with no
+    scratch, and the N = 16 one with AGPRs to spare.  On top of the compiler's own resource report, the listing is scanned
+    (scripts/isa_accd_scan.py): no scratch instruction, every AGPR the asm blocks read is parked by an asm block, and --
+    in a listing with phase markers -- on the hot path of an ADMM iteration no compiler-generated instruction writes an
+    AGPR the asm blocks of that path read (the Delta^-1 rows stay put between factorisations) and nothing goes to scratch."""
     import re
     import shutil
     import subprocess
+    import sys
 
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read()
     mpcflags = re.search(r"^MPCFLAGS\s*:=\s*(.*)$", mk, re.M).group(1).split()
-    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-pass-failed",
-                        "-Rpass-analysis=kernel-resource-usage"] + mpcflags +
-                       [os.path.join(csrc, "mpc_kernel.hip"), "-o", os.devnull], capture_output=True, text=True, timeout=600)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-pass-failed"] + mpcflags
+    ship = str(tmp_path / "mpc_ship.s")
+    r = subprocess.run(base + ["-Rpass-analysis=kernel-resource-usage", os.path.join(csrc, "mpc_kernel.hip"), "-o", ship],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     blk = r.stderr.split("mpc_solve_kernelILi1ELb1ELb0E")[1]
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
     agprs = int(re.search(r"AGPRs: (\d+)", blk).group(1))
     vspill = int(re.search(r"VGPRs Spill: (\d+)", blk).group(1))
     assert scratch == 0 and vspill == 0 and agprs < 256, (scratch, vspill, agprs)
-    # every other instantiation of the kernel (N < 16, N = 32 / 17..31 with two wavefronts, the sequence forms): no scratch
-    # either, and accumulation registers to spare (round 3: two lambdas around the neighbour exchange were enough to push
-    # the N = 32 sequence kernel to 256 AGPRs + 28 B of scratch)
+    # every other instantiation of the kernel (N < 16, N = 32 / 17..31 with two wavefronts, the sequence and the
+    # time-sliced forms): no scratch either (round 3: two lambdas around the neighbour exchange were enough to push the
+    # N = 32 sequence kernel to 256 AGPRs + 28 B of scratch)
     seen = 0
     for part in r.stderr.split("Function Name: ")[1:]:
         if "mpc_solve_kernelILi" not in part.splitlines()[0]:
@@ -98,6 +104,25 @@ def test_shipped_mpc_kernel_spills_nothing_to_scratch():
         vs = int(re.search(r"VGPRs Spill: (\d+)", part).group(1))
         assert sc == 0 and vs == 0 and ag <= 256, (name, sc, vs, ag)
     assert seen == 10, seen  # plain + sequence forms of <1,full>, <1,short>, <2,full>, <2,short>, time-sliced forms of the <2,*>
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_accd_scan
+
+    res = isa_accd_scan.scan_file(ship)
+    assert len(res) == 10
+    for name, findings, st in res:
+        assert not findings, findings[:3]
+        assert st["asm_read"] == 120 and st["scratch"] == 0, (name, st)
+    # the hot-path check needs the phase markers (asm comments) in the listing: a second build with -DQRW_MARK_PHASES
+    mark = str(tmp_path / "mpc_mark.s")
+    r = subprocess.run(base + ["-DQRW_MARK_PHASES", os.path.join(csrc, "mpc_kernel.hip"), "-o", mark], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = isa_accd_scan.scan_file(mark)
+    assert len(res) == 10
+    for name, findings, st in res:
+        hot = [f for f in findings if "hot path" in f or "phase markers" in f or "no asm block writes" in f]
+        assert not hot, hot[:3]  # (the markers themselves may cost the tightest variant a spill outside the hot path)
+        assert st["hot"] and st["hot"]["asm_read"] == 72, (name, st)
 
 
 def _build_cabi_demo(tmp_path):
