@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "controller_glue.h"
 #include "qrw_kernels.h"
@@ -647,7 +648,6 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b, long l
   if (remain_dirty) s(L.remain) = remain;
   PP(9);
 }
-#undef FSI
 
 __global__ __launch_bounds__(64) void planner_kernel(PlannerArgs a) {
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -674,6 +674,480 @@ __global__ __launch_bounds__(64) void control_pre_kernel(ControllerArgs cu, Plan
   if (with_wbc_inputs) glue::wbc_inputs(cw, b);
   PP(10);
 }
+
+
+// ---- the same fused head with ONE QUAD PER INSTANCE (lane = 4 * instance + foot; 16 instances per wavefront, as wbc_kernel):
+// the per-foot work -- footstep table column, foot trajectory, foot command of the WBC target assembly -- runs on the
+// foot's own lane, the shared scalar work (state update, gait matrices as bit masks, yaw sines) redundantly on all four, the
+// stores are dealt to the lanes, and the three pieces hand over through REGISTERS instead of through their HBM operands.
+// One thread per instance was 64 wavefronts of pure latency on 1024 SIMDs (57 % of the wave cycles parked at s_waitcnt,
+// DESIGN.md 4.4); per lane this does about a third of the instructions and a quarter of the dependent HBM round trips.
+// Arithmetic, expression by expression, is that of update_state / planner_body / wbc_inputs above (parity: the fused and
+// the separate control loops are both checked against the chained CPU oracles, tests/test_gpu_controller.py).
+namespace {
+// FootTrajectoryGenerator::updateFootPosition for ONE foot held in scalars (the expressions of update_foot_position<J>)
+struct FootLane {
+  double t0s, tsw, ax[6], ay[6], pos[3], vel[3], acc[3];
+};
+__device__ __forceinline__ void update_foot_lane(FootLane& f, const PlannerArgs& a, const double tf[3], double& fttgt0, double& fttgt1,
+                                                 bool& fttgt_dirty) {
+  const double ddx0 = f.acc[0], ddy0 = f.acc[1];
+  const double dx0 = f.vel[0], dy0 = f.vel[1];
+  const double x0 = f.pos[0], y0 = f.pos[1];
+  const double t = f.t0s, d = f.tsw, dt = a.dt_wbc;
+#define P(x_, n_) ipow<n_>(x_)
+  if (t < d - a.lock_time) {
+    const double den1 = (2 * P((t - d), 2) * (P(t, 3) - 3 * P(t, 2) * d + 3 * t * P(d, 2) - P(d, 3)));
+    const double den2 = (2 * (P(t, 2) - 2 * t * d + P(d, 2)) * (P(t, 3) - 3 * P(t, 2) * d + 3 * t * P(d, 2) - P(d, 3)));
+#pragma unroll
+    for (int ax = 0; ax < 2; ax++) {
+      const double dd0 = ax ? ddy0 : ddx0, d0 = ax ? dy0 : dx0, p0 = ax ? y0 : x0, tg = tf[ax];
+      double* A = ax ? f.ay : f.ax;
+      A[0] = (dd0 * P(t, 2) - 2 * dd0 * t * d - 6 * d0 * t + dd0 * P(d, 2) + 6 * d0 * d + 12 * p0 - 12 * tg) / den1;
+      A[1] = (30 * t * tg - 30 * t * p0 - 30 * d * p0 + 30 * d * tg - 2 * P(t, 3) * dd0 - 3 * P(d, 3) * dd0 +
+              14 * P(t, 2) * d0 - 16 * P(d, 2) * d0 + 2 * t * d * d0 + 4 * t * P(d, 2) * dd0 + P(t, 2) * d * dd0) / den1;
+      A[2] = (P(t, 4) * dd0 + 3 * P(d, 4) * dd0 - 8 * P(t, 3) * d0 + 12 * P(d, 3) * d0 + 20 * P(t, 2) * p0 -
+              20 * P(t, 2) * tg + 20 * P(d, 2) * p0 - 20 * P(d, 2) * tg + 80 * t * d * p0 - 80 * t * d * tg +
+              4 * P(t, 3) * d * dd0 + 28 * t * P(d, 2) * d0 - 32 * P(t, 2) * d * d0 - 8 * P(t, 2) * P(d, 2) * dd0) / den1;
+      A[3] = -(P(d, 5) * dd0 + 4 * t * P(d, 4) * dd0 + 3 * P(t, 4) * d * dd0 + 36 * t * P(d, 3) * d0 -
+               24 * P(t, 3) * d * d0 + 60 * t * P(d, 2) * p0 + 60 * P(t, 2) * d * p0 - 60 * t * P(d, 2) * tg -
+               60 * P(t, 2) * d * tg - 8 * P(t, 2) * P(d, 3) * dd0 - 12 * P(t, 2) * P(d, 2) * d0) / den2;
+      A[4] = -(2 * P(d, 5) * d0 - 2 * t * P(d, 5) * dd0 - 10 * t * P(d, 4) * d0 + P(t, 2) * P(d, 4) * dd0 +
+               4 * P(t, 3) * P(d, 3) * dd0 - 3 * P(t, 4) * P(d, 2) * dd0 - 16 * P(t, 2) * P(d, 3) * d0 +
+               24 * P(t, 3) * P(d, 2) * d0 - 60 * P(t, 2) * P(d, 2) * p0 + 60 * P(t, 2) * P(d, 2) * tg) / den1;
+      A[5] = (2 * tg * P(t, 5) - dd0 * P(t, 4) * P(d, 3) - 10 * tg * P(t, 4) * d + 2 * dd0 * P(t, 3) * P(d, 4) +
+              8 * d0 * P(t, 3) * P(d, 3) + 20 * tg * P(t, 3) * P(d, 2) - dd0 * P(t, 2) * P(d, 5) -
+              10 * d0 * P(t, 2) * P(d, 4) - 20 * p0 * P(t, 2) * P(d, 3) + 2 * d0 * t * P(d, 5) +
+              10 * p0 * t * P(d, 4) - 2 * p0 * P(d, 5)) / den2;
+    }
+    fttgt0 = tf[0];
+    fttgt1 = tf[1];
+    fttgt_dirty = true;
+  }
+  const double dz = (P((d / 2), 3) * P((d - d / 2), 3));
+  const double Az0 = -a.max_height / dz, Az1 = (3 * d * a.max_height) / dz, Az2 = -(3 * P(d, 2) * a.max_height) / dz,
+               Az3 = (P(d, 3) * a.max_height) / dz;
+  const double ev = t + dt;
+  if (t < 0.0 || t > d) {
+    f.pos[0] = x0; f.pos[1] = y0;
+    f.vel[0] = 0.0; f.vel[1] = 0.0;
+    f.acc[0] = 0.0; f.acc[1] = 0.0;
+  } else {
+#pragma unroll
+    for (int ax = 0; ax < 2; ax++) {
+      const double* A = ax ? f.ay : f.ax;
+      const double A0 = A[0], A1 = A[1], A2 = A[2], A3 = A[3], A4 = A[4], A5 = A[5];
+      f.pos[ax] = A5 + A4 * ev + A3 * P(ev, 2) + A2 * P(ev, 3) + A1 * P(ev, 4) + A0 * P(ev, 5);
+      f.vel[ax] = A4 + 2 * A3 * ev + 3 * A2 * P(ev, 2) + 4 * A1 * P(ev, 3) + 5 * A0 * P(ev, 4);
+      f.acc[ax] = 2 * A3 + 3 * 2 * A2 * ev + 4 * 3 * A1 * P(ev, 2) + 5 * 4 * A0 * P(ev, 3);
+    }
+  }
+  f.vel[2] = 3 * Az3 * P(ev, 2) + 4 * Az2 * P(ev, 3) + 5 * Az1 * P(ev, 4) + 6 * Az0 * P(ev, 5);
+  f.acc[2] = 2 * 3 * Az3 * ev + 3 * 4 * Az2 * P(ev, 2) + 4 * 5 * Az1 * P(ev, 3) + 5 * 6 * Az0 * P(ev, 4);
+  f.pos[2] = Az3 * P(ev, 3) + Az2 * P(ev, 4) + Az1 * P(ev, 5) + Az0 * P(ev, 6);
+#undef P
+}
+__device__ __forceinline__ double quadmax_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  double o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));
+  v = fmax(v, o);
+  lo = __double2loint(v); hi = __double2hiint(v);
+  o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));
+  return fmax(v, o);
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu, PlannerArgs a, ControllerArgs cw, int with_wbc_inputs) {
+  const int tix = blockIdx.x * 64 + threadIdx.x;
+  const int b = tix >> 2, j = tix & 3;
+  if (b >= a.B) return;  // whole quads leave together
+  const int Ng = a.N_gait, k = a.k;
+  const Lay L = make_layout(Ng);
+  PS s;
+  s.base = a.ps + b;
+  s.stride = (size_t)a.B;
+  const glue::CS cs = glue::state_of(cu, b);
+  const double dtw = cu.dt_wbc;
+
+  // ================= operands of all three pieces, ahead of the first store =================
+  double jv[6], vf6[6], rpy_in[3], vf_mine[3], qf_mine[3];
+  {
+    const double* pj = cu.in0 + (size_t)b * 6;
+    const double* pq = cu.in1 + (size_t)b * 19;
+    const double* pv = cu.in2 + (size_t)b * 18;
+    const double* pr = cu.in3 + (size_t)b * 3;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { jv[i] = pj[i]; vf6[i] = pv[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rpy_in[i] = pr[i]; vf_mine[i] = pv[6 + 3 * j + i]; qf_mine[i] = pq[7 + 3 * j + i]; }
+  }
+  const double qf2 = cu.in1[(size_t)b * 19 + 2];
+  const double yaw0 = cs(glue::cYAW), qx0 = cs(glue::cQX), qy0 = cs(glue::cQY);
+  Gm past, cur, des;
+  gm_load(s, L.past, past);
+  gm_load(s, L.cur, cur);
+  gm_load(s, L.des, des);
+  double newphase = s(L.newphase), remain = s(L.remain);
+  double cf[3], fs1[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) { cf[r] = s(L.cf + r * 4 + j); fs1[r] = s(FSI(1, r, j)); }
+  const double otgt_z = s(L.otgt + 8 + j);
+  FootLane ft;
+  ft.t0s = s(L.t0s + j); ft.tsw = s(L.tsw + j);
+#pragma unroll
+  for (int r = 0; r < 6; r++) { ft.ax[r] = s(L.ax + r * 4 + j); ft.ay[r] = s(L.ay + r * 4 + j); }
+#pragma unroll
+  for (int r = 0; r < 3; r++) { ft.pos[r] = s(L.pos + r * 4 + j); ft.vel[r] = s(L.vel + r * 4 + j); ft.acc[r] = s(L.acc + r * 4 + j); }
+  const double nfeet_s = s(L.nfeet);
+  double feet_s[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) feet_s[jj] = s(L.feet + jj);
+  const int code = a.code ? a.code[b] : a.code_scalar;
+  // WBC target assembly: the previous commands of this foot, the PD references of this foot's joints, the MPC forces of this foot
+  double pcmd[3] = {0, 0, 0}, vcmd[3] = {0, 0, 0}, qdes[3] = {0, 0, 0}, vdes[3] = {0, 0, 0}, xf_f[3] = {0, 0, 0};
+  if (with_wbc_inputs) {
+    const int N = cw.n_steps;
+    const double* xf = cw.in0 + (size_t)b * 24 * N;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      pcmd[r] = cs(glue::cPCMD + r * 4 + j); vcmd[r] = cs(glue::cVCMD + r * 4 + j);
+      qdes[r] = cs(glue::cQDES + 3 * j + r); vdes[r] = cs(glue::cVDES + 3 * j + r);
+      xf_f[r] = xf[(12 + 3 * j + r) * N];
+    }
+  }
+
+  // ================= Controller.updateState (scripts/Controller.py:381-426) =================
+  const double c0 = cos(yaw0), s0 = sin(yaw0);
+  const double qx = qx0 + (c0 * jv[0] + -s0 * jv[1]) * dtw;
+  const double qy = qy0 + (s0 * jv[0] + c0 * jv[1]) * dtw;
+  const double yaw = yaw0 + jv[5] * dtw;
+  double q7[7];
+  q7[0] = qx; q7[1] = qy; q7[2] = qf2;
+  {
+    const double sr = sin(rpy_in[0] / 2.), cr = cos(rpy_in[0] / 2.), sp = sin(rpy_in[1] / 2.), cp = cos(rpy_in[1] / 2.),
+                 sy = sin(yaw / 2.), cy = cos(yaw / 2.);
+    q7[3] = sr * cp * cy - cr * sp * sy;
+    q7[4] = cr * sp * cy + sr * cp * sy;
+    q7[5] = cr * cp * sy - sr * sp * cy;
+    q7[6] = cr * cp * cy + sr * sp * sy;
+  }
+  double hv[6];
+  {
+    const double cr = cos(rpy_in[0]), sr = sin(rpy_in[0]), cp = cos(rpy_in[1]), sp = sin(rpy_in[1]);
+    const double R[9] = {cp, sp * sr, sp * cr, 0.0, cr, -sr, -sp, cp * sr, cp * cr};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      hv[r] = R[r * 3] * vf6[0] + R[r * 3 + 1] * vf6[1] + R[r * 3 + 2] * vf6[2];
+      hv[3 + r] = R[r * 3] * vf6[3] + R[r * 3 + 1] * vf6[4] + R[r * 3 + 2] * vf6[5];
+    }
+  }
+  const double cyw = cos(yaw), syw = sin(yaw);
+  {
+    double* q = cu.out0 + (size_t)b * 19;
+    double* v = cu.out1 + (size_t)b * 18;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { q[7 + 3 * j + i] = qf_mine[i]; v[6 + 3 * j + i] = vf_mine[i]; }
+    if (j == 0) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) q[i] = q7[i];
+      cs(glue::cQX) = qx; cs(glue::cQY) = qy; cs(glue::cYAW) = yaw;
+    } else if (j == 1) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) { v[i] = vf6[i]; cs(glue::cVREF + i) = jv[i]; }
+    } else if (j == 2) {
+      double* o = cu.out2 + (size_t)b * 6;
+#pragma unroll
+      for (int i = 0; i < 6; i++) o[i] = hv[i];
+      if (cu.out3) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cu.out3[(size_t)b * 6 + i] = jv[i];
+      }
+    } else if (cu.out4) {
+      double* o = cu.out4 + (size_t)b * 12;
+      o[0] = cyw; o[1] = -syw; o[2] = 0; o[3] = syw; o[4] = cyw; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = 1;
+      o[9] = qx; o[10] = qy; o[11] = 0.0;
+    }
+  }
+  const double* vr = jv;  // the planners' reference velocity is the joystick's (Controller.py:222-236 via updateState)
+  double rpy[3];
+  quat_to_rpy(q7 + 3, rpy);
+
+  // ================= Gait::updateGait (all four lanes hold the whole matrices as bit masks) =================
+  if (j == 0) {
+    s(L.isstatic) = (code == 4) ? 1.0 : 0.0;
+    if (code == 4)
+      for (int i = 0; i < 7; i++) s(L.qstatic + i) = q7[i];
+  }
+  gait_update(past, cur, des, a, k, code, newphase);
+  if (j == 0 && k % a.k_mpc == 0) s(L.newphase) = newphase;
+
+  // ================= FootstepPlanner::updateFootsteps, this lane's foot =================
+  double last_call = -1.0;  // order key of this lane's last getPhaseDuration call (table: 4 i + j, trajectory: 4 N_gait + j)
+  const bool ct0 = gbit(cur, 0, j);
+  if (a.refresh != 0 && newphase != 0.0 && ct0) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) cf[r] = fs1[r];
+  }
+  {
+    const double ry = a.dt_wbc * vr[5];
+    const double c = cos(ry), sn = sin(ry);
+    const double dpx = a.dt_wbc * vr[0], dpy = a.dt_wbc * vr[1];
+    if (ct0) {
+      const double x = cf[0] - dpx, y = cf[1] - dpy;
+      cf[0] = c * x + sn * y;
+      cf[1] = -sn * x + c * y;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) s(L.cf + r * 4 + j) = cf[r];
+  double row[3], tg[2] = {0.0, 0.0};
+  bool found = false;
+  double* fo = (a.fsteps) ? a.fsteps + (size_t)b * Ng * 12 : nullptr;
+#pragma unroll
+  for (int r = 0; r < 3; r++) row[r] = ct0 ? cf[r] : 0.0;
+  const double w = vr[5];
+  double dtc_prev = a.dt_wbc * a.k_footsteps;
+  const double cross0 = hv[1] * vr[5] - hv[2] * vr[4], cross1 = hv[2] * vr[3] - hv[0] * vr[5];
+  bool live = true;
+  for (int i = 0; i < Ng; i++) {
+    if (i > 0) {
+      live = live && !rz(cur, i);
+      const bool gp = gbit(cur, i - 1, j), gc = gbit(cur, i, j);
+      double nrow[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) nrow[r] = (live && gp && gc) ? row[r] : 0.0;
+      if (live) {
+        if (!gp && gc) {
+          const double yawp = w * dtc_prev;
+          const double c = cos(yawp), sn = sin(yawp);
+          double dxp, dyp;
+          if (w != 0) {
+            dxp = (hv[0] * sn + hv[1] * (c - 1.0)) / w;
+            dyp = (hv[1] * sn - hv[0] * (c - 1.0)) / w;
+          } else {
+            dxp = hv[0] * dtc_prev;
+            dyp = hv[1] * dtc_prev;
+          }
+          const double t_stance = phase_duration(past, cur, des, a, i, j, true, remain);
+          last_call = (double)(4 * i + j);
+          double nf[3];
+          const double cr[3] = {cross0, cross1, 0.0};
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            double v = t_stance * 0.5 * hv[r];
+            v += a.k_feedback * (hv[r] - vr[r]);
+            v += 0.5 * sqrt(a.h_ref / a.g) * cr[r];
+            nf[r] = v;
+          }
+          nf[0] = fmax(fmin(nf[0], a.L), -a.L);
+          nf[1] = fmax(fmin(nf[1], a.L), -a.L);
+          nf[0] += a.shoulders[0 * 4 + j];
+          nf[1] += a.shoulders[1 * 4 + j];
+          nf[2] = 0.0;
+          nrow[0] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
+          nrow[1] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
+          nrow[2] = (0.0 * nf[0] + 0.0 * nf[1] + 1.0 * nf[2]) + 0.0;
+        }
+        dtc_prev = dtc_prev + a.dt_mpc;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) row[r] = nrow[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      s(FSI(i, r, j)) = row[r];
+      if (fo) fo[i * 12 + 3 * j + r] = row[r];
+    }
+    if (!found && (row[0] != 0.0 || i == Ng - 1)) {
+      found = true;
+      tg[0] = row[0];
+      tg[1] = row[1];
+    }
+  }
+  double otgt[3];
+  {
+    const double c = cos(rpy[2]), sn = sin(rpy[2]);
+    s(L.tgt + j) = tg[0];
+    s(L.tgt + 4 + j) = tg[1];
+    s(L.tgt + 8 + j) = 0.0;
+    otgt[0] = (c * tg[0] - sn * tg[1]) + q7[0];
+    otgt[1] = (sn * tg[0] + c * tg[1]) + q7[1];
+    otgt[2] = otgt_z;
+    s(L.otgt + j) = otgt[0];
+    s(L.otgt + 4 + j) = otgt[1];
+  }
+
+  // ================= FootTrajectoryGenerator::update, this lane's foot =================
+  {
+    unsigned swing = 0;
+    bool run;
+    if ((k % a.k_mpc) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!gbit(cur, 0, i)) swing |= 1u << i;
+      const int nf = __popc(swing);
+      if (swing & (1u << j)) s(L.feet + __popc(swing & ((1u << j) - 1u))) = (double)j;
+      if (j == 0) s(L.nfeet) = (double)nf;
+      run = nf != 0;
+      if (swing & (1u << j)) {
+        const double tsw = phase_duration(past, cur, des, a, 0, j, false, remain);
+        last_call = (double)(4 * Ng + j);
+        ft.tsw = tsw;
+        const double value = tsw - (remain * a.k_mpc - ((k + 1) % a.k_mpc)) * a.dt_wbc - a.dt_wbc;
+        ft.t0s = fmax(0.0, value);
+      }
+    } else {
+      const int nf = (int)nfeet_s;
+      run = nf != 0;
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        if (jj < nf) swing |= 1u << (int)feet_s[jj];
+      if (swing & (1u << j)) ft.t0s = fmax(0.0, ft.t0s + a.dt_wbc);
+    }
+    double ftt0 = 0.0, ftt1 = 0.0;
+    bool ftt_dirty = false;
+    if (run && (swing & (1u << j))) update_foot_lane(ft, a, otgt, ftt0, ftt1, ftt_dirty);
+    if (ftt_dirty) { s(L.fttgt + j) = ftt0; s(L.fttgt + 4 + j) = ftt1; }
+    s(L.t0s + j) = ft.t0s; s(L.tsw + j) = ft.tsw;
+#pragma unroll
+    for (int r = 0; r < 6; r++) { s(L.ax + r * 4 + j) = ft.ax[r]; s(L.ay + r * 4 + j) = ft.ay[r]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) { s(L.pos + r * 4 + j) = ft.pos[r]; s(L.vel + r * 4 + j) = ft.vel[r]; s(L.acc + r * 4 + j) = ft.acc[r]; }
+    if (a.feet_pva) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        a.feet_pva[(size_t)b * 36 + r * 4 + j] = ft.pos[r];
+        a.feet_pva[(size_t)b * 36 + 12 + r * 4 + j] = ft.vel[r];
+        a.feet_pva[(size_t)b * 36 + 24 + r * 4 + j] = ft.acc[r];
+      }
+    }
+  }
+  // remainingTime_ is what the LAST getPhaseDuration call of the sequential program left (src/Gait.cpp:141-182)
+  {
+    const double mx = quadmax_d(last_call);
+    if (last_call >= 0.0 && last_call == mx) s(L.remain) = remain;
+  }
+
+  // ================= StatePlanner::computeReferenceStates: the horizon steps dealt to the four lanes =================
+  double xr1_6 = 0.0, xr1_7 = 0.0;  // rows 6, 7 of column 1 (the WBC target assembly reads them back)
+  if (a.xref) {
+    double* X = a.xref + (size_t)b * 12 * (a.n_steps + 1);
+    const int n = a.n_steps, ld = n + 1;
+    {  // column 0: three rows per lane
+      const double col0[12] = {0.0, 0.0, q7[2], rpy[0], rpy[1], 0.0, hv[0], hv[1], hv[2], hv[3], hv[4], hv[5]};
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int e = 3 * j + r;
+        double v = col0[0];
+#pragma unroll
+        for (int q = 1; q < 12; q++) v = (e == q) ? col0[q] : v;
+        X[e * ld] = v;
+      }
+    }
+    const double T_mpc = a.T_mpc;
+    const int n_out = (a.xref_steps > 0 && a.xref_steps < n) ? a.xref_steps : n;
+    for (int i = j; i < n_out; i += 4) {
+      const double dtv = (n == 1 || i == n - 1) ? T_mpc : a.dt_mpc + i * ((T_mpc - a.dt_mpc) / (n - 1));
+      const double yw = vr[5] * dtv;
+      const double sy = sin(yw), cy = cos(yw);
+      double x, y;
+      if (vr[5] != 0) {
+        x = (vr[0] * sy + vr[1] * (cy - 1.0)) / vr[5];
+        y = (vr[1] * sy - vr[0] * (cy - 1.0)) / vr[5];
+      } else {
+        x = vr[0] * dtv;
+        y = vr[1] * dtv;
+      }
+      const double v6 = vr[0] * cy - vr[1] * sy, v7 = vr[0] * sy + vr[1] * cy;
+      X[0 * ld + 1 + i] = x + 0.0;
+      X[1 * ld + 1 + i] = y + 0.0;
+      X[2 * ld + 1 + i] = a.h_ref + a.z_average;
+      X[3 * ld + 1 + i] = 0.0;
+      X[4 * ld + 1 + i] = 0.0;
+      X[5 * ld + 1 + i] = yw;
+      X[6 * ld + 1 + i] = v6;
+      X[7 * ld + 1 + i] = v7;
+      X[8 * ld + 1 + i] = 0.0; X[9 * ld + 1 + i] = 0.0; X[10 * ld + 1 + i] = 0.0;
+      X[11 * ld + 1 + i] = vr[5];
+      if (i == 0) { xr1_6 = v6; xr1_7 = v7; }
+    }
+  }
+
+  // ================= remaining planner outputs / state =================
+  if (a.gait) {
+    double* o = a.gait + (size_t)b * Ng * 4;
+    for (int i = 0; i < Ng; i++) o[i * 4 + j] = gbit(cur, i, j) ? 1.0 : 0.0;
+  }
+  if (a.contacts) a.contacts[(size_t)b * 4 + j] = gbit(cur, 0, j) ? 1.0 : 0.0;
+  if (a.target) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) a.target[(size_t)b * 12 + r * 4 + j] = otgt[r];
+  }
+  {
+    const unsigned long long pc = (j == 0) ? past.c[0] : (j == 1) ? past.c[1] : (j == 2) ? past.c[2] : past.c[3];
+    const unsigned long long cc = (j == 0) ? cur.c[0] : (j == 1) ? cur.c[1] : (j == 2) ? cur.c[2] : cur.c[3];
+    const unsigned long long dc = (j == 0) ? des.c[0] : (j == 1) ? des.c[1] : (j == 2) ? des.c[2] : des.c[3];
+    s(L.past + j) = __longlong_as_double((long long)pc);
+    s(L.cur + j) = __longlong_as_double((long long)cc);
+    s(L.des + j) = __longlong_as_double((long long)dc);
+  }
+
+  // ================= WBC target assembly (scripts/Controller.py:258-296), this lane's foot =================
+  if (with_wbc_inputs) {
+    const double h_ref = cw.h_ref;
+    double* xw = cw.out0 ? cw.out0 + (size_t)b * 24 : nullptr;
+    if (xw) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) xw[12 + 3 * j + r] = xf_f[r];
+      if (j == 0) {  // lane 0 computed horizon step 1 of xref (rows 6..11 of column 1: v6, v7, 0, 0, 0, w_ref)
+        xw[0] = dtw * xr1_6;
+        xw[1] = dtw * xr1_7;
+        xw[2] = h_ref; xw[3] = 0.0; xw[4] = 0.0;
+        xw[5] = dtw * vr[5];
+        xw[6] = xr1_6; xw[7] = xr1_7; xw[8] = 0.0; xw[9] = 0.0; xw[10] = 0.0; xw[11] = vr[5];
+      }
+    }
+    double* qw = cw.out1 + (size_t)b * 19;
+    double* bv = cw.out2 + (size_t)b * 18;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { qw[7 + 3 * j + r] = qdes[r]; bv[6 + 3 * j + r] = vdes[r]; }
+    if (j == 0) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) qw[i] = (i == 2) ? h_ref : (i == 6) ? 1.0 : 0.0;
+    } else if (j == 1) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) bv[i] = jv[i];
+    }
+    if (cw.out3) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) cw.out3[(size_t)b * 12 + 3 * j + r] = xf_f[r];
+    }
+    const double wv[3] = {jv[3], jv[4], jv[5]};
+    const double vl[3] = {jv[0], jv[1], jv[2]};
+    double* fc = cw.out4 + (size_t)b * 12;
+    const size_t pl = (size_t)cw.B * 12;
+    double wxp[3], wxwxp[3], wxv[3];
+    glue::cross3(wv, pcmd, wxp);
+    glue::cross3(wv, wxp, wxwxp);
+    glue::cross3(wv, vcmd, wxv);
+    const double ra[3] = {cyw * ft.acc[0] + syw * ft.acc[1], -syw * ft.acc[0] + cyw * ft.acc[1], ft.acc[2]};
+    const double rv[3] = {cyw * ft.vel[0] + syw * ft.vel[1], -syw * ft.vel[0] + cyw * ft.vel[1], ft.vel[2]};
+    const double dp[3] = {ft.pos[0] - 0.0 - qx, ft.pos[1] - 0.0 - qy, ft.pos[2] - h_ref - 0.0};
+    const double rp[3] = {cyw * dp[0] + syw * dp[1], -syw * dp[0] + cyw * dp[1], dp[2]};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double an = ra[r] - wxwxp[r] - 2 * wxv[r];
+      const double vn = (rv[r] - vl[r]) - wxp[r];
+      fc[2 * pl + r * 4 + j] = an;
+      fc[pl + r * 4 + j] = vn;
+      fc[r * 4 + j] = rp[r];
+      cs(glue::cVCMD + r * 4 + j) = vn;
+      cs(glue::cPCMD + r * 4 + j) = rp[r];
+    }
+  }
+}
+
+#undef FSI
 
 #ifdef QRW_PROFILE_PRE
 static void pre_prof_dump() {  // diagnostic build only: synchronises the device
@@ -720,7 +1194,16 @@ int control_pre_launch(const ControllerArgs& cu, const PlannerArgs& p, const Con
   static int calls = 0;
   if (++calls % 50 == 0) pre_prof_dump();
 #endif
-  hipLaunchKernelGGL(control_pre_kernel, dim3((p.B + 63) / 64), dim3(64), 0, stream, cu, p, cw, with_wbc_inputs);
+  // one quad per instance (control_pre_quad_kernel); QRW_PRE_QUAD=0 selects the one-thread-per-instance form (A/B timing).
+  // The quad form covers what qrw_control_pre asks for: all four planners on every call, no external trajectory targets.
+  const char* qe = getenv("QRW_PRE_QUAD");  // read per call: the A/B scripts flip it between two handles of one process
+  const bool quad = !(qe && atoi(qe) == 0);
+  const int want = kPlanGait | kPlanFootsteps | kPlanTraj | kPlanState;
+  if (quad && p.mode == want && !p.target_in && p.q_ld == 19 && p.q7 == cu.out0 && p.hv == cu.out2 && p.vref == cu.out3 &&
+      (!with_wbc_inputs || (cw.in1 == p.xref && cw.in2 == p.feet_pva && cw.in3 == cu.out1)) && p.N_gait <= 64)
+    hipLaunchKernelGGL(control_pre_quad_kernel, dim3((4 * p.B + 63) / 64), dim3(64), 0, stream, cu, p, cw, with_wbc_inputs);
+  else
+    hipLaunchKernelGGL(control_pre_kernel, dim3((p.B + 63) / 64), dim3(64), 0, stream, cu, p, cw, with_wbc_inputs);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -171,7 +171,7 @@ def _closed_loop(oracle_mod, mode, fused, cfg, iters):
             for i, (ref, tol) in enumerate(((P, 0), (D, 0), (q_des, 1e-4), (v_des, 1e-4), (t8, 1e-4))):
                 err = np.max(np.abs(got[b, i] - ref)) / max(1.0, np.max(np.abs(ref)))
                 worst = max(worst, err)
-                assert err <= tol, (k, b, i, err)
+                assert err <= tol, (k, b, i, err, "gpu", got[b, i].tolist(), "oracle", np.asarray(ref).tolist())
             nq[b, 7:], nv[b, 6:] = q_des, v_des  # perfect tracking of the oracle's targets
         qf, vf = nq, nv
     st = ctl.stats()
