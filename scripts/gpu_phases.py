@@ -1,7 +1,8 @@
 """Phase-cycle breakdown of the MPC kernel (diagnostic build with -DQRW_PROFILE_PHASES)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["QRW_HIP_LIB"] = os.path.join(ROOT, "build", "libqrw_hip_prof.so")
+os.environ["QRW_HIP_LIB"] = os.environ.get("QRW_HIP_LIB", os.path.join(ROOT, "build", "libqrw_hip_prof.so"))
+os.environ["QRW_PREEMPT_CHUNK"] = "0"  # whole solves per workgroup: the counters of a time-sliced solve are those of its last slice only
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, time
 import qrw_hip, synth

@@ -10,6 +10,7 @@ cd $R
 python3 bench.py > $OUT/${ROUND}_bench_line.json 2> $OUT/bench.err
 echo "bench done"
 python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_mixed.json 2> $OUT/bench32.err
+QRW_PREEMPT_CHUNK=0 python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_mixed_unsliced.json 2>> $OUT/bench32.err
 echo "bench n32 done"
 python3 bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_b1.json 2>> $OUT/bench.err
 python3 bench.py --batch 256 --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_b256.json 2>> $OUT/bench.err
@@ -22,6 +23,8 @@ cp $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_b409
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32 -o st -- python3 $R/bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_under_rocprof.json 2> $OUT/stats32.err
 cp $(find $OUT/stats32 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_n32_mixed.csv
 cp $(find $OUT/stats32 -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_n32.csv
+QRW_PREEMPT_CHUNK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32u -o st -- python3 $R/bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/stats32u.err
+cp $(find $OUT/stats32u -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_n32_mixed_unsliced.csv
 echo "rocprof stats done"
 cd $R && ROUND=$ROUND bash scripts/pmc_profile.sh > $OUT/pmc.log 2>&1 && cp $R/gpurun_out/pmc_$ROUND/summary.json $OUT/${ROUND}_pmc_summary_bench_b4096.json && cp $R/gpurun_out/pmc_$ROUND/stamp.json $OUT/${ROUND}_pmc_stamp_bench_b4096.json
 echo "pmc done"
