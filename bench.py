@@ -504,7 +504,7 @@ def dry_ranks(args):
             print(json.dumps({"dry_ranks": n, "failed_rank": r, "rc": p.returncode}), flush=True)
             return 1
         per_rank.append({"local_rank": r, "device_ordinal_used": line.get("device_ordinal"), "shard_first_instance": line.get("shard_first_instance"),
-                         "steps_per_s": line["value"], "launch_ms_mean": line["roofline"]["launch_ms_mean"],
+                         "steps_per_s": line["value"], "launch_ms_mean": line.get("roofline", {}).get("launch_ms_mean"),
                          "input_gen_s": line.get("input_gen_s"), "handle_create_s": line.get("handle_create_s"),
                          "ranks_seen": line.get("collective", {}).get("ranks_seen"),
                          "gathered_block_check": line.get("collective", {}).get("gathered_block_check"),

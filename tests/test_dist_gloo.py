@@ -136,3 +136,24 @@ def test_bench_collective_path_on_one_rccl_rank():
     assert "RCCL" in c["backend"] and c["ranks_seen"] == [0] and c["gathered_block_check"] is True
     assert c["bytes_per_rank_per_step"] == 256 * 12 * 8 and c["no_collective_steps_per_s"] > 0
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_bench_dry_ranks_preflight_on_cpu_stub():
+    """`bench.py --dry-ranks 3`: the parent that walks every rank's path one rank at a time, here with
+    QRW_BENCH_STUB=1 (no kernels) and gloo: per-rank lines are collected, each rank gets ITS shard of the instances."""
+    r, line = _run_bench({"QRW_BENCH_STUB": "1", "QRW_DIST_BACKEND": "gloo"}, "--dry-ranks", "3", "--steps", "2", "--warmup", "1",
+                         "--batch", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["dry_ranks"] == 3 and [p["local_rank"] for p in line["per_rank"]] == [0, 1, 2]
+    assert all(p["ranks_seen"] == [0] and p["gathered_block_check"] is True for p in line["per_rank"])
+
+
+@pytest.mark.gpu
+def test_bench_dry_ranks_preflight_real_kernels():
+    """The same pre-flight with the real HIP path and a one-rank RCCL group per rank: handle creation incl. the self-test,
+    the rank's own shard (b0 = rank x batch), both timed regions, JSON assembly."""
+    r, line = _run_bench({}, "--dry-ranks", "2", "--steps", "2", "--warmup", "1", "--batch", "128")
+    assert r.returncode == 0, r.stderr[-3000:]
+    pr = line["per_rank"]
+    assert [p["shard_first_instance"] for p in pr] == [0, 128] and all(p["device_ordinal_used"] == 0 for p in pr)
+    assert all("RCCL" in p["backend"] and p["gathered_block_check"] is True and p["launch_ms_mean"] > 0 for p in pr)
