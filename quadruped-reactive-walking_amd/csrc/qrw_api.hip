@@ -330,6 +330,10 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
     a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
     HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
     HIP_OK(hipMemsetAsync(h->pre_ctr, 0, qrw::kPreCtrWords * sizeof(unsigned), (hipStream_t)stream), "qrw_mpc_solve: counter reset");
+    // a solve that a given-up queue left unfinished (never expected; qrw_mpc_get_stats reports it) must not leave the previous
+    // call's numbers in the caller's buffer: NaN (all-ones bytes) until the finishing slice writes the result (~10 us per call)
+    HIP_OK(hipMemsetAsync(d_out, 0xFF, (size_t)h->cfg.batch * 24 * (size_t)h->cfg.n_steps * sizeof(double), (hipStream_t)stream),
+           "qrw_mpc_solve: result prefill");
     if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   } else if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
