@@ -615,7 +615,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   // its instance by index starts the solve whatever an aborted launch may have left behind)
   int it_resume = 0;
   if constexpr (PRE) {
-    if ((int)blockIdx.x >= a.B) it_resume = a.pause_it[b];
+    // (agent-scope atomic loads: what another workgroup of THIS launch stored must never be served from a scalar or stale cache)
+    if ((int)blockIdx.x >= a.B) it_resume = __hip_atomic_load(&a.pause_it[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const bool resumed = PRE && it_resume > 0;
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
@@ -671,7 +672,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   bool parked = false;  // PRE: this chunk ended before the solve did
 #define ST(item) st[(item)*T + tid]
 
-  if (!first && !a.flags[b]) {  // reference would dereference an un-setup OSQP workspace
+  // (agent-scope atomic load: in a sequence launch the flag may have been set by another workgroup of this launch)
+  if (!first && !__hip_atomic_load(&a.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {  // reference would dereference an un-setup OSQP workspace
     if (tid == 0) {
       a.status[b] = kStatusNotSetup;
       a.iters[b] = 0;
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 5; c++) zeC[c] = resumed ? zC[c] : rho * Ec[c] * zC[c];
-    if (resumed) rho_updates = a.rho_updates[b];
+    if (resumed) rho_updates = __hip_atomic_load(&a.rho_updates[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // PRE: a solve parked with an unchanged rho resumes with the loop constants it had: the re-basing of theta / wD in the
   // factor block must then be the identity.  As written it is not: `zu_new - zeU` is contracted into one fma, which returns
