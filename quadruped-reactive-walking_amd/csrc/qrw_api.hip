@@ -699,7 +699,20 @@ extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_J
   a.mode = 3;
   a.in0 = s.in(h_M, B * 324); a.in1 = s.in(h_Jc, B * 216); a.in2 = s.in(h_f_cmd, B * 12); a.in3 = s.in(h_RNEA, B * 6);
   a.out0 = s.out(B * 12); a.out1 = s.out(B * 6); a.out2 = h_H ? s.out(B * 144) : nullptr;
+  // M[:6,:6] diagonal in every instance (what scripts/QP_WBC.py:93 hands over): the kernel inverts it in place; otherwise the
+  // general pseudoInverse<> of include/qrw/InvKin.hpp:60-66 is computed first (pinv6_kernel)
+  bool diagonal = true;
+  for (size_t b = 0; b < B && diagonal; b++)
+    for (int i = 0; i < 6 && diagonal; i++)
+      for (int c = 0; c < 6; c++)
+        if (i != c && h_M[b * 324 + i * 18 + c] != 0.0) { diagonal = false; break; }
+  double* d_yinv = nullptr;
+  if (!diagonal) d_yinv = s.out(B * 36);
   if (!s.ok) return fail(-12, "qrw_qpwbc_host: staging failed");
+  if (d_yinv) {
+    if (qrw::pinv6_launch(a.in0, d_yinv, (int)B, nullptr) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
+    a.in4 = d_yinv;
+  }
   if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
   HIP_OK(hipDeviceSynchronize(), "sync");
   if (!(s.back(h_f_res, a.out0, B * 12) && s.back(h_ddq_res, a.out1, B * 6) && s.back(h_H, a.out2, B * 144)))

@@ -116,6 +116,7 @@ struct WbcArgs {
 };
 
 int wbc_launch(const WbcArgs& a, hipStream_t stream);
+int pinv6_launch(const double* d_M18, double* d_Yinv, int B, hipStream_t stream);  // pseudoInverse<> of M[:6,:6], [B][6][6]
 
 }  // namespace qrw
 

@@ -665,26 +665,54 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   if (a.mode == 3) {  // QPWBC::run from caller-supplied M (diagonal), Jc, f_cmd, RNEA (qrw_qpwbc_host)
     const double* M = a.in0 + (size_t)bb * 324;
     const double* Jc = a.in1 + (size_t)bb * 216;
-    double Yd[6], Yi[6], smax = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { Yd[i] = M[i * 18 + i]; smax = fmax(smax, fabs(Yd[i])); }
-    const double tol = 2.220446049250313e-16 * 6.0 * smax;  // pseudoInverse<>, InvKin.hpp:60-66
-#pragma unroll
-    for (int i = 0; i < 6; i++) Yi[i] = (fabs(Yd[i]) > tol) ? 1.0 / Yd[i] : 0.0;
     double Aj[6][3], fc[3], xf[6], gamma[6];
 #pragma unroll
     for (int t = 0; t < 3; t++) fc[t] = a.in2[bb * 12 + 3 * j + t];
+    if (a.in4) {
+      // general Y: Yinv = pseudoInverse(M[:6,:6]) (include/qrw/InvKin.hpp:60-66) from pinv6_kernel; A = Yinv X, gamma = Yinv (X f - RNEA)
+      const double* Yv = a.in4 + (size_t)bb * 36;
+      double X[6][3], d6[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      double s_ = 0.0;
+      for (int i = 0; i < 6; i++) {
+        double s_ = 0.0;
 #pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const double xv = Jc[(3 * j + t) * 18 + i];
-        Aj[i][t] = Yi[i] * xv;
-        s_ += xv * fc[t];
+        for (int t = 0; t < 3; t++) { X[i][t] = Jc[(3 * j + t) * 18 + i]; s_ += X[i][t] * fc[t]; }
+        xf[i] = quad_sum(s_);
+        d6[i] = xf[i] - a.in3[bb * 6 + i];
       }
-      xf[i] = quad_sum(s_);
-      gamma[i] = Yi[i] * (xf[i] - a.in3[bb * 6 + i]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double g_ = 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) Aj[i][t] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const double y = Yv[i * 6 + m];
+          g_ += y * d6[m];
+#pragma unroll
+          for (int t = 0; t < 3; t++) Aj[i][t] += y * X[m][t];
+        }
+        gamma[i] = g_;
+      }
+    } else {
+      double Yd[6], Yi[6], smax = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { Yd[i] = M[i * 18 + i]; smax = fmax(smax, fabs(Yd[i])); }
+      const double tol = 2.220446049250313e-16 * 6.0 * smax;  // pseudoInverse<>, InvKin.hpp:60-66, of a diagonal block
+#pragma unroll
+      for (int i = 0; i < 6; i++) Yi[i] = (fabs(Yd[i]) > tol) ? 1.0 / Yd[i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const double xv = Jc[(3 * j + t) * 18 + i];
+          Aj[i][t] = Yi[i] * xv;
+          s_ += xv * fc[t];
+        }
+        xf[i] = quad_sum(s_);
+        gamma[i] = Yi[i] * (xf[i] - a.in3[bb * 6 + i]);
+      }
     }
     QpIo io;
     qp_build(Aj, gamma, fc, j, io);
@@ -970,6 +998,66 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       if (j == 0 && a.c_err) a.c_err[bb] = err;
     }
   }
+}
+
+// pseudoInverse<> of the reference (include/qrw/InvKin.hpp:60-66: JacobiSVD, V diag(1/s_i if s_i > eps max(r,c) s_0 else 0) U^H)
+// for the 6 x 6 block M[:6,:6] of the stand-alone QPWBC::run (src/QPWBC.cpp:486-493), any matrix: one-sided (Hestenes) Jacobi
+// SVD, one thread per instance -- rotate pairs of columns of A = Y (and of V) until all columns are orthogonal; then s_i = |a_i|,
+// U = A diag(1/s), and V Sigma^+ U' = V diag(1/s_i^2) A'.  The pseudo-inverse is unique, so this agrees with any other accurate
+// SVD to rounding (tests: numpy.linalg.pinv with the reference's threshold, and the oracle on symmetric blocks).  Not on the hot
+// path: the reference's only caller masks the block to its diagonal (scripts/QP_WBC.py:93), which wbc_kernel handles directly.
+__global__ __launch_bounds__(64) void pinv6_kernel(const double* M18, double* Yinv, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const double* M = M18 + (size_t)b * 324;
+  double A[6][6], V[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int c = 0; c < 6; c++) { A[i][c] = M[i * 18 + c]; V[i][c] = (i == c) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < 5; p++)
+      for (int q = p + 1; q < 6; q++) {
+        double al = 0.0, be = 0.0, ga = 0.0;
+        for (int k = 0; k < 6; k++) { al += A[k][p] * A[k][p]; be += A[k][q] * A[k][q]; ga += A[k][p] * A[k][q]; }
+        if (ga == 0.0 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+        rotated = true;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int k = 0; k < 6; k++) {
+          const double ap = A[k][p], aq = A[k][q];
+          A[k][p] = c * ap - sn * aq;
+          A[k][q] = sn * ap + c * aq;
+          const double vp = V[k][p], vq = V[k][q];
+          V[k][p] = c * vp - sn * vq;
+          V[k][q] = sn * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double s2[6], smax = 0.0;
+  for (int c = 0; c < 6; c++) {
+    double n2 = 0.0;
+    for (int k = 0; k < 6; k++) n2 += A[k][c] * A[k][c];
+    s2[c] = n2;
+    smax = fmax(smax, sqrt(n2));
+  }
+  const double tol = 2.220446049250313e-16 * 6.0 * smax;
+  double* Yo = Yinv + (size_t)b * 36;
+  for (int i = 0; i < 6; i++)
+    for (int m = 0; m < 6; m++) {
+      double acc = 0.0;
+      for (int c = 0; c < 6; c++) {
+        const double inv = (sqrt(s2[c]) > tol) ? 1.0 / s2[c] : 0.0;
+        acc += V[i][c] * inv * A[m][c];
+      }
+      Yo[i * 6 + m] = acc;
+    }
+}
+
+int pinv6_launch(const double* d_M18, double* d_Yinv, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(pinv6_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_M18, d_Yinv, B);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int wbc_launch(const WbcArgs& a, hipStream_t stream) {

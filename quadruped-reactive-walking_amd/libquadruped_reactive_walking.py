@@ -81,14 +81,9 @@ class QPWBC:
         self._H = np.zeros((12, 12))
 
     def run(self, M, Jc, f_cmd, RNEA, k_contact):
+        # M[:6,:6] is pseudo-inverted as src/QPWBC.cpp:486 does (include/qrw/InvKin.hpp:60-66): directly inside the kernel for
+        # the diagonal block the reference's caller always passes (scripts/QP_WBC.py:93), by a Jacobi SVD on the device otherwise
         M = np.asarray(M, dtype=np.float64)
-        Y = M[:6, :6]
-        if np.any(Y - np.diag(np.diag(Y)) != 0.0):
-            # src/QPWBC.cpp:486 pseudo-inverts the full 6x6 block (include/qrw/InvKin.hpp:60-66, JacobiSVD); the kernel
-            # implements the case the reference's caller always produces — the block masked to its diagonal
-            # (scripts/QP_WBC.py:93) — and refuses anything else rather than silently using the diagonal only.
-            raise ValueError("QPWBC.run: M[:6,:6] must be diagonal (scripts/QP_WBC.py:93 masks it); the general "
-                             "pseudo-inverse of include/qrw/InvKin.hpp:60-66 is not implemented on the device")
         f, d, H = self._b.qpwbc_host(M[None], np.asarray(Jc, dtype=np.float64)[None],
                                      np.asarray(f_cmd, dtype=np.float64).reshape(1, 12),
                                      np.asarray(RNEA, dtype=np.float64).reshape(1, 6))

@@ -73,24 +73,52 @@ def test_gait_initialize_raises_like_the_reference():
         g.initialize(0.02, 0.32, 0.32, 10)
 
 
-def test_qpwbc_refuses_a_non_diagonal_base_block(oracle_mod):
-    """src/QPWBC.cpp:486 pseudo-inverts the full 6x6 block (include/qrw/InvKin.hpp:60-66); the device path implements the
-    masked-diagonal case the reference's caller always produces (scripts/QP_WBC.py:93) and must refuse anything else."""
+def test_qpwbc_general_pseudo_inverse_of_the_base_block(oracle_mod):
+    """src/QPWBC.cpp:486 pseudo-inverts the full 6x6 block M[:6,:6] (pseudoInverse<>, include/qrw/InvKin.hpp:60-66: JacobiSVD,
+    singular values below eps * 6 * s_0 dropped).  The reference's caller masks the block to its diagonal (scripts/QP_WBC.py:93),
+    which the kernel inverts in place; any other block goes through a Jacobi SVD on the device.  Checked through H = A'Q1 A + Q2
+    with A = pinv(Y) X against numpy.linalg.pinv with the reference's threshold (an independent LAPACK SVD) for a symmetric
+    positive definite block (the unmasked CRBA), an upper-triangular one (what Pinocchio's crba fills), a non-symmetric one and a
+    rank-deficient one, and through f_res / ddq_res against the oracle's QPWBC on the symmetric block."""
     import libquadruped_reactive_walking as lrw
 
     q = np.zeros(19)
     q[6] = 1.0
     q[7:] = [0.1, 0.7, -1.4, 0.0, 0.6, -1.3, 0.0, -0.7, 1.4, -0.1, -0.7, 1.4]
-    M = oracle_mod.crba(q)  # unmasked: the base block has off-diagonal terms
+    M0 = oracle_mod.crba(q)  # unmasked: the base block has off-diagonal terms
     Jc = oracle_mod.feet_jacobians(q)
-    qp = lrw.QPWBC()
     f_cmd = np.tile([0.0, 0.0, 6.0], 4)
     RNEA = np.array([0.1, -0.2, 24.0, 0.05, 0.02, -0.01])
-    with pytest.raises(ValueError, match="diagonal"):
-        qp.run(M, Jc, f_cmd, RNEA, np.zeros(4))
-    Mm = M.copy()
+    rng = np.random.default_rng(7)
+    sym = M0.copy()
+    sym[:6, :6] = 0.5 * (M0[:6, :6] + M0[:6, :6].T)
+    tri = M0.copy()
+    tri[:6, :6] = np.triu(sym[:6, :6])
+    gen = M0.copy()
+    gen[:6, :6] = sym[:6, :6] + 0.05 * rng.standard_normal((6, 6))
+    sing = M0.copy()
+    Y = sym[:6, :6].copy()
+    Y[:, 5] = Y[:, 4]  # two equal columns: rank 5
+    sing[:6, :6] = Y
+    X = Jc[:, :6].T
+    for name, M in (("symmetric", sym), ("upper triangular", tri), ("non-symmetric", gen), ("rank-deficient", sing)):
+        qp = lrw.QPWBC()
+        assert qp.run(M, Jc, f_cmd, RNEA, np.zeros(4)) == 0
+        A = np.linalg.pinv(M[:6, :6], rcond=6 * np.finfo(float).eps) @ X
+        H = A.T @ (0.1 * np.eye(6)) @ A + 5.0 * np.eye(12)
+        assert np.allclose(qp.get_H(), H, rtol=1e-9, atol=1e-9), (name, np.abs(qp.get_H() - H).max())
+        if name == "symmetric":
+            rq = oracle_mod.QPWBC()
+            rq.run(M, Jc, f_cmd, RNEA, np.zeros(4))
+            assert np.allclose(qp.get_f_res().ravel(), np.asarray(rq.get_f_res()).ravel(), rtol=1e-6, atol=1e-8)
+            assert np.allclose(qp.get_ddq_res().ravel(), np.asarray(rq.get_ddq_res()).ravel(), rtol=1e-6, atol=1e-8)
+    # the masked block (the hot path's case) still goes the direct way and gives the same as the general routine on it
+    Mm = M0.copy()
     Mm[:6, :6] *= np.eye(6)
+    qp = lrw.QPWBC()
     assert qp.run(Mm, Jc, f_cmd, RNEA, np.zeros(4)) == 0
+    A = np.diag(1.0 / np.diag(Mm[:6, :6])) @ X
+    assert np.allclose(qp.get_H(), A.T @ (0.1 * np.eye(6)) @ A + 5.0 * np.eye(12), rtol=1e-12, atol=1e-12)
 
 
 def test_tensor_on_wrong_device_or_dtype_is_refused():
