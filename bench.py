@@ -520,8 +520,12 @@ def mpc_source_stamp():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("mpc_kernel.hip", "chain_sweep.h", "qrw_kernels.h", "qrw_device.h"):
-        h.update(open(os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc")
+    for f in ("mpc_kernel.hip", "chain_sweep.h", "qrw_device.h"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    k = open(os.path.join(csrc, "qrw_kernels.h")).read()  # of the shared header only the MPC state layout
+    i = k.index("enum MpcStateItem")
+    h.update(k[i:k.index("};", i)].encode())
     return h.hexdigest()
 
 
