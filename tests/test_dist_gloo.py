@@ -157,3 +157,15 @@ def test_bench_dry_ranks_preflight_real_kernels():
     pr = line["per_rank"]
     assert [p["shard_first_instance"] for p in pr] == [0, 128] and all(p["device_ordinal_used"] == 0 for p in pr)
     assert all("RCCL" in p["backend"] and p["gathered_block_check"] is True and p["launch_ms_mean"] > 0 for p in pr)
+
+
+def test_bench_own_multi_rank_branch_eight_ranks_gloo():
+    """BASELINE config 5's rank count (8 ranks x batch shard) through bench.py's own N > 1 branch on CPU tensors over gloo
+    (QRW_BENCH_STUB=1, no kernels): launcher, shard offsets, per-step all-gather pipeline, both timed regions, JSON."""
+    r, line = _run_bench({"QRW_BENCH_STUB": "1", "QRW_DIST_BACKEND": "gloo"}, "--gpus", "8", "--steps", "2", "--warmup", "1",
+                         "--batch", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "batch-sharded x8"
+    c = line["collective"]
+    assert c["ranks_seen"] == list(range(8)) and c["gathered_block_check"] is True
+    assert abs(line["value"] - 8 * 4 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
