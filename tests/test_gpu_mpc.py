@@ -590,3 +590,50 @@ def test_twostance_closed_loop_grows_at_the_monodromy_rate_on_the_hip_path():
         trot_kat.NOT_CENTERED = old
     growth = err[160] / err[96]
     assert 1.17 < rho < 1.23 and 0.85 * rho ** 4 < growth < 1.15 * rho ** 4, (rho, growth)
+
+
+def test_time_sliced_launch_edge_cases(synth_mod, monkeypatch):
+    """The time-sliced launch where its bookkeeping could go wrong: instances that are not set up (num_iter != 0 on their
+    first call: NaN result, status NOT_SETUP, counted as finished), per-instance iteration arguments, a compute-unit-masked
+    stream with fewer resident slots than instances (every later workgroup of the grid waits on the queue), and a second
+    stream's solves beside it.  Everything must equal the unsliced launch (iteration counts / status exactly, results to
+    rounding), every call must complete (no stale numbers: the result buffer is pre-filled with NaN)."""
+    import torch
+
+    import qrw_hip
+
+    N, B, N_gait = 32, 600, 36
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=("trot", "walk", "bounding"), seed0=20320000)
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", "0")
+    plain = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", "400")
+    monkeypatch.setenv("QRW_PREEMPT_MIN_BATCH", "8")
+    sliced, other = (qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N) for _ in range(2))
+    dev = torch.device("cuda", 0)
+    n_cu = qrw_hip.device_cu_count(0)
+    masked, rest = qrw_hip.CuStream(0, 0, 96), qrw_hip.CuStream(0, 96, n_cu - 96)  # 192 resident slots for 600 instances
+    for s in range(3):
+        d = sb.step(s)
+        x, f = torch.from_numpy(d["xref"]).to(dev), torch.from_numpy(d["fsteps"]).to(dev)
+        ni = torch.full((B,), s, dtype=torch.int32, device=dev)
+        if s == 0:
+            ni[5::97] = 3  # these instances see num_iter != 0 before any set-up call
+        a = plain.mpc_solve(x, f, ni).cpu().numpy()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(rest.torch):
+            other.mpc_solve(x, f, ni)
+        with torch.cuda.stream(masked.torch):
+            b = sliced.mpc_solve(x, f, ni)
+        torch.cuda.synchronize()
+        b = b.cpu().numpy()
+        sa, sb_ = plain.mpc_stats(), sliced.mpc_stats()
+        assert np.array_equal(sa["iters"], sb_["iters"]) and np.array_equal(sa["status"], sb_["status"]), s
+        assert np.array_equal(np.isnan(a), np.isnan(b)), s
+        ok = ~np.isnan(a)
+        assert np.abs(a[ok] - b[ok]).max() <= 1e-8 * np.abs(a[ok]).max(), s
+        if s == 0:
+            assert (sb_["status"][5::97] == -100).all() and np.isnan(b[5::97]).all() and np.isfinite(b[0]).all()
+        else:
+            assert (sb_["status"] != -100).sum() == B - len(range(5, B, 97))  # the un-set-up ones stay so (reference: a null workspace)
+    masked.close()
+    rest.close()
