@@ -10,7 +10,7 @@ from Controller import Controller_batch
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 mp = len(sys.argv) > 2
-B, N, dev = 4096, 16, torch.device("cuda", 0)
+B, N, dev = 4096, int(os.environ.get("QRW_LOOP_N", "16")), torch.device("cuda", 0)
 rng = np.random.default_rng(11)
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
 
@@ -25,7 +25,7 @@ def new_vref(scale):
 
 
 with torch.cuda.stream(torch.cuda.Stream(dev)):
-    ctl = Controller_batch(B, q_init, multiprocessing=mp)
+    ctl = Controller_batch(B, q_init, multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=max(20, N + 4))
     vref = new_vref(0.5)
     qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
     qf[:, 7:] = torch.from_numpy(q_init).to(dev)
