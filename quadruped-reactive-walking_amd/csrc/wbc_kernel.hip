@@ -292,9 +292,11 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
       nE[c] = v;
     }
 #pragma unroll
-    for (int t = 0; t < 3; t++) D[t] *= 1.0 / sqrt(limit_scaling(nD[t]));
+    // rsqrt (1-2 ulp) instead of OSQP's 1.0 / sqrt(): the equilibration is a preconditioner, iteration counts and results
+    // still agree with the oracle (tests/test_gpu_wbc.py), and 80 square-root-and-divide chains per call go (as mpc_kernel.hip)
+    for (int t = 0; t < 3; t++) D[t] *= rsqrt(limit_scaling(nD[t]));
 #pragma unroll
-    for (int c = 0; c < 5; c++) E[c] *= 1.0 / sqrt(limit_scaling(nE[c]));
+    for (int c = 0; c < 5; c++) E[c] *= rsqrt(limit_scaling(nE[c]));
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       Dall[t] = quad_bcast<0>(D[t]); Dall[3 + t] = quad_bcast<1>(D[t]);
