@@ -51,6 +51,7 @@ struct alignas(16) MpcLdsDis {
   double sDg[32 * 12];                   // c*w + sigma/Dx^2 per step (factor phase)
   double sRed[4];
   unsigned long long sBal[2];
+  double sPre[8];
 };
 static_assert(sizeof(MpcLdsDis) <= 81920, "two N = 32 instances per compute unit need <= 80 KB each");
 static_assert(36 * 12 + 12 * 16 >= 4 * 144, "the four hand-off buffers of the factor phase overlay sX + sC");

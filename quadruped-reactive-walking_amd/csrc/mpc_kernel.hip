@@ -59,6 +59,7 @@ struct alignas(16) MpcLdsT {
   double sB[kMatSz];     // Delta_k (inverted in place)
   double sRed[4];        // cross-wavefront reductions
   unsigned long long sBal[2];
+  double sPre[8];        // time-sliced launch: (primal residual, its norm, dual residual, its norm) of the last two adaptive-rho tests
 };
 
 // Workgroup barrier of the ADMM loop.  One wavefront per instance: the LDS executes a wavefront's operations in order, so
@@ -491,39 +492,87 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
   }
 }
 
-// ---- PRE: round-robin time slicing of one call's solves inside one launch (qrw_mpc_solve at N > 16, batch > resident slots).
+// ---- PRE: time slicing of one call's solves inside one launch (qrw_mpc_solve at N > 16, batch > resident slots).
 // A launch's workgroups are started in index order on the 512 resident slots (two-wavefront instances) and each runs to the
-// end of its solve, 150..4000 ADMM iterations that nobody can predict well enough (3.5 % of the N = 32 mixed-gait solves
-// hit max_iter, never the same instances; profiles/r3_lpt_sim_n32.txt): whatever the order, some long solves start in the
-// last round and the launch ends 1.26-1.29 x later than work / slots.  Here a workgroup runs AT MOST `pre_chunk`
+// end of its solve, 150..4000 ADMM iterations that nobody can predict BEFOREHAND well enough (3.5 % of the N = 32 mixed-gait
+// solves hit max_iter, never the same instances; profiles/r3_lpt_sim_n32.txt): whatever the order, some long solves start in
+// the last round and the launch ends 1.26-1.29 x later than work / slots.  Here a workgroup runs AT MOST `pre_chunk`
 // iterations (cut at a multiple of 200, where OSQP's adaptive-rho test sits), then parks the instance -- the ADMM loop
 // variables go into the state slots the warm start uses, bit for bit -- and queues it; the grid has B * pre_cmax
-// workgroups, the first B take the instances directly, every later one takes the oldest parked instance from ONE FIFO
-// (round robin: all solves advance together, so when the slots outnumber the unfinished solves those are the genuinely long
-// ones, near their end).  Simulated on recorded counts: 1.10 x instead of 1.28 x.  A resumed solve re-assembles and
-// re-equilibrates (deterministic: same inputs), reloads the loop variables, re-factors for the rho it was parked with and
+// workgroups, the first B take the instances directly, every later one takes a parked instance.  A resumed solve re-assembles
+// and re-equilibrates (deterministic: same inputs), reloads the loop variables, re-factors for the rho it was parked with and
 // goes on with iteration it0 + 1: the same arithmetic as the uninterrupted solve, so iteration counts, status and results
-// are identical (the parity tests run through this path).
-//   pre_ctr words: 0 head (next slot to take), 16 tail (next slot to fill), 32 finished instances, 33 error, 34 progress
+// are identical (the parity tests run through this path), WHATEVER the order the parked solves are taken in.
+//   Which parked solve next (round 3, second half): one FIFO (round robin: all solves advance together, so when the slots
+// outnumber the unfinished solves those are the genuinely long ones, near their end) ends 1.09 x after work / slots.  But once
+// a solve RUNS its length can be predicted: ADMM converges linearly, the residuals fall by a constant factor per iteration
+// between rho updates, so with r = max(primal residual / its tolerance, dual residual / its tolerance) at two consecutive
+// adaptive-rho tests the remaining iterations are ~ 200 ln r / ln(r_prev / r) (log-error 0.23 at iteration 600, 0.12 at 1200 on
+// the recorded traces, scripts/gpu_res_trace.py).  So: a solve parked after its FIRST slice goes to level 0 (a FIFO: the
+// prediction at iteration 600 still misses the slow mode that takes over later in about 1 % of the solves, and one such solve
+// left for the end costs more than all the ordering gains); from the second park on its level is 1 + (levels - 2 -
+// predicted remaining / pre_bin), most remaining first, re-predicted at every park.  A workgroup takes from the lowest-numbered
+// level that has a solve: longest-remaining-first on 400-iteration bins, 1.03 x in the simulation (scripts/pre_priority_sim.py).
+//   Queues: pre_queue[level][slot]; per level a head (next slot to take) and a tail (next slot to fill).  A taker first draws
+// a TICKET T and waits until more than T solves have been parked in total (`parks`): from then on a solve is there for it --
+// tickets are drawn by resident workgroups only, every ticket below `parks` belongs to a workgroup that takes exactly one
+// solve, and a level's tail is advanced before `parks` -- so it pops with compare-and-swap from the best non-empty level and
+// simply looks again when another gated taker was faster (nobody polls a head: takers wait on `parks` alone, and only at the
+// end of the launch, when the queues are empty).  No deadlock: a waiting taker waits for a park that a RUNNING slice makes; if
+// every resident workgroup waited there would be no parked solve left (each has its ticket's taker) and none running, i.e. all
+// have finished, which the takers see (`finished` == B) and leave.
+//   pre_ctr words: 0 tickets, 16 parks, 32 finished instances, 33 error, 34 progress, kPreLevelWord + 2 l / + 2 l + 1: head / tail of level l
 constexpr int kPreHead = 0, kPreTail = 16, kPreDone = 32, kPreErr = 33, kPreProgress = 34;
-static_assert(kPreProgress < kPreCtrWords, "pre_ctr too small");
+static_assert(kPreProgress < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
 template <int NW>
 __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
   int task = -1;
   if (tid == 0) {
-    const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (slot < (unsigned)a.pre_cap) {
+    const unsigned ticket = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket < (unsigned)a.pre_cap) {
       SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
-      const int* q = a.pre_queue + slot;
+      bool gated = false;
       for (;;) {
-        task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (task >= 0) break;
+        if (q_load(&a.pre_ctr[kPreTail]) > ticket) { gated = true; break; }
         if (q_load(&a.pre_ctr[kPreDone]) >= (unsigned)a.B) break;  // every instance has finished: nothing will be parked any more
         if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;               // somebody gave up already: do not wait another 2 s each
         __builtin_amdgcn_s_sleep(32);
         if (clock.expired()) {  // 2 s without any chunk of the launch ending: give up, loudly
           __hip_atomic_store(&a.pre_ctr[kPreErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
+        }
+      }
+      if (gated) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int* q = nullptr;
+        while (!q) {
+          for (int l = 0; l < a.pre_levels && !q; l++) {
+            unsigned* head = &a.pre_ctr[kPreLevelWord + 2 * l];
+            unsigned h = q_load(head);
+            while (h < q_load(head + 1)) {
+              if (__hip_atomic_compare_exchange_strong(head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                q = a.pre_queue + (size_t)l * a.pre_cap + h;
+                break;
+              }
+            }
+          }
+          if (!q) {  // another gated taker was faster on what this one saw: its own solve is (about to be) in some level
+            __builtin_amdgcn_s_sleep(8);
+            if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;
+            if (clock.expired()) {
+              __hip_atomic_store(&a.pre_ctr[kPreErr], 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+        }
+        while (q) {  // the slot's store follows its reservation closely
+          task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (task >= 0) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (clock.expired()) {
+            __hip_atomic_store(&a.pre_ctr[kPreErr], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
         }
       }
       if (task >= 0) {
@@ -543,18 +592,31 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
   }
   return task;
 }
-// end of a chunk: parked (queue the instance) or finished (count it)
+// priority level of a solve parked at iteration `iter` (tid 0): r, r_prev = max(primal residual / tolerance, dual residual /
+// tolerance) at this and at the previous adaptive-rho test of this slice (0: none)
+__device__ __forceinline__ int pre_level(const MpcArgs& a, int iter, int it_resume, double r, double r_prev) {
+  if (a.pre_levels < 2 || it_resume == 0) return 0;  // one FIFO / parked after the first slice
+  const int nl = a.pre_levels - 1;
+  float rem = (float)(4000 - iter);
+  if (r_prev > r && r > 1.0) rem = fminf(rem, 200.0f * __logf((float)r) / __logf((float)(r_prev / r)));
+  int bin = (int)(rem / (float)a.pre_bin);
+  bin = bin < 0 ? 0 : (bin > nl - 1 ? nl - 1 : bin);
+  return 1 + (nl - 1 - bin);
+}
+// end of a chunk: parked (queue the instance in `level`) or finished (count it)
 template <int NW>
-__device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool parked, int tid) {
+__device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool parked, int level, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores of the instance's state have left
   if constexpr (NW > 1) __syncthreads();
   if (tid == 0) {
     if (parked) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreTail], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (slot < (unsigned)a.pre_cap) __hip_atomic_store(&a.pre_queue[slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreLevelWord + 2 * level + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < (unsigned)a.pre_cap) __hip_atomic_store(&a.pre_queue[(size_t)level * a.pre_cap + slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else __hip_atomic_store(&a.pre_ctr[kPreErr], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the level's tail is out before the gate opens for one more taker
+      __hip_atomic_fetch_add(&a.pre_ctr[kPreTail], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __hip_atomic_fetch_add(&a.pre_ctr[kPreDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -619,6 +681,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     if ((int)blockIdx.x >= a.B) it_resume = __hip_atomic_load(&a.pause_it[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const bool resumed = PRE && it_resume > 0;
+  if constexpr (PRE) { if (tid < 8) L.sPre[tid] = 0.0; }
+#ifdef QRW_TRACE_RES
+  if (!resumed && a.prof && tid < kMpcProfItems) a.prof[(size_t)b * kMpcProfItems + tid] = 0.0;
+#endif
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
   const bool act = FULL ? true : (k < N);
@@ -1386,8 +1452,18 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           rho_updates++;
           need_factor = true;
         }
+#ifdef QRW_TRACE_RES  // diagnostics: how far from termination the solve is at every adaptive-rho test (scripts/gpu_res_trace.py)
+        if (tid == 0 && a.prof && iter <= 4000) {
+          double* tr = a.prof + (size_t)b * kMpcProfItems + (iter / 200 - 1) * 3;
+          tr[0] = pri_res / (eps_abs + eps_rel * last_np); tr[1] = dua_res / (eps_abs + eps_rel * last_nd); tr[2] = rho;
+        }
+#endif
         if constexpr (PRE) {  // end of this workgroup's time slice: park the solve here (after the rho test, before iteration iter + 1)
           if (iter - it_resume >= a.pre_chunk && iter < max_iter) parked = true;
+          if (tid == 0) {  // how far from termination (the queue's priority level is predicted from two consecutive tests, at the park)
+            double* pr = &L.sPre[(iter / 200 & 1) * 4];
+            pr[0] = pri_res; pr[1] = last_np; pr[2] = dua_res; pr[3] = last_nd;
+          }
         }
       }
       PH(7);
@@ -1398,7 +1474,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   PH(7);
 #ifdef QRW_PROFILE_PHASES
-  if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * 10 + i] = (double)ph_acc[i];
+  if (tid == 0 && a.prof) for (int i = 0; i < 10; i++) a.prof[(size_t)b * kMpcProfItems + i] = (double)ph_acc[i];
 #endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved && !parked) {
@@ -1479,7 +1555,18 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   }  // set up
   if constexpr (SEQ) seq_finish_task<NW>(a, b, seq_s, tid);
-  if constexpr (PRE) pre_end_chunk<NW>(a, b, parked, tid);
+  if constexpr (PRE) {
+    int level = 0;
+    if (parked && tid == 0) {  // (registers are free here: the divisions and logarithms stay out of the ADMM loop)
+      const int it = a.pause_it[b];
+      const double* p1 = &L.sPre[(it / 200 & 1) * 4];
+      const double* p0 = &L.sPre[((it / 200 & 1) ^ 1) * 4];
+      const double r1 = fmax(p1[0] / (1e-6 + 1e-6 * p1[1]), p1[2] / (1e-6 + 1e-6 * p1[3]));
+      const double r0 = (p0[1] > 0.0 || p0[3] > 0.0) ? fmax(p0[0] / (1e-6 + 1e-6 * p0[1]), p0[2] / (1e-6 + 1e-6 * p0[3])) : 0.0;
+      level = pre_level(a, it, it_resume, r1, r0);
+    }
+    pre_end_chunk<NW>(a, b, parked, level, tid);
+  }
   }
 #undef QRW_UNPARK
 #undef ST
@@ -1589,7 +1676,8 @@ bool mpc_build_is_timing_experiment() {
 
 // preemptive launch (N > 16 only): B * pre_cmax workgroups, the caller has reset pre_queue (-1) and pre_ctr (0) on the stream
 int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream) {
-  if (a.N <= 16 || a.N > kMpcMaxN || !a.pre_queue || !a.pre_ctr || !a.pause_it || a.pre_chunk < 200 || a.pre_cmax < 1) return -1;
+  if (a.N <= 16 || a.N > kMpcMaxN || !a.pre_queue || !a.pre_ctr || !a.pause_it || a.pre_chunk < 200 || a.pre_cmax < 1 || a.pre_levels < 1 ||
+      a.pre_levels > kPreMaxLevels || a.pre_bin < 1) return -1;
   const unsigned blocks = (unsigned)a.B * (unsigned)a.pre_cmax;
   if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false, true>), dim3(blocks), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false, true>), dim3(blocks), dim3(128), 0, stream, a);

@@ -56,7 +56,7 @@ struct qrw_handle_s {
   int* pre_queue = nullptr;
   unsigned* pre_ctr = nullptr;
   int* pause_it = nullptr;
-  int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0;
+  int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0, pre_levels = 1, pre_bin = 400;
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -256,7 +256,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->mpc_rho, B * sizeof(double));
   ALLOC(h->mpc_pri, B * sizeof(double));
   ALLOC(h->mpc_dua, B * sizeof(double));
-  ALLOC(h->mpc_prof, B * 10 * sizeof(double));
+  ALLOC(h->mpc_prof, B * qrw::kMpcProfItems * sizeof(double));
   if (N > 16) {
     // round-robin time slicing of the solves of one call (mpc_kernel.hip, PRE): slices of QRW_PREEMPT_CHUNK iterations
     // (default 600, rounded up to a multiple of 200; 0 switches it off), used when the batch exceeds the resident slots
@@ -272,7 +272,15 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
       if (const char* mb = getenv("QRW_PREEMPT_MIN_BATCH")) h->pre_min_batch = atoi(mb);  // tests: slice small batches too
       ALLOC(h->pause_it, B * sizeof(int));
       ALLOC(h->pre_ctr, qrw::kPreCtrWords * sizeof(unsigned));
-      ALLOC(h->pre_queue, B * (size_t)(h->pre_cmax > 1 ? h->pre_cmax - 1 : 1) * sizeof(int));
+      // priority levels of the parked solves (mpc_kernel.hip, PRE): QRW_PREEMPT_LEVELS = 1 is one FIFO (plain round robin),
+      // the default 9 = first-slice FIFO + 8 levels of QRW_PREEMPT_BIN (400) predicted remaining iterations each
+      h->pre_levels = qrw::kPreMaxLevels;
+      if (const char* le = getenv("QRW_PREEMPT_LEVELS")) h->pre_levels = atoi(le);
+      if (h->pre_levels < 1) h->pre_levels = 1;
+      if (h->pre_levels > qrw::kPreMaxLevels) h->pre_levels = qrw::kPreMaxLevels;
+      if (const char* be = getenv("QRW_PREEMPT_BIN")) h->pre_bin = atoi(be);
+      if (h->pre_bin < 25) h->pre_bin = 25;
+      ALLOC(h->pre_queue, (size_t)h->pre_levels * B * (size_t)(h->pre_cmax > 1 ? h->pre_cmax - 1 : 1) * sizeof(int));
     }
   }
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
@@ -328,7 +336,8 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
     // more instances than resident slots at N > 16: the solves are time-sliced round robin inside the launch (same results)
     a.pre_chunk = h->pre_chunk; a.pre_cmax = h->pre_cmax; a.pre_cap = h->cfg.batch * (h->pre_cmax - 1);
     a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
-    HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
+    a.pre_levels = h->pre_levels; a.pre_bin = h->pre_bin;
+    HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_levels * a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
     HIP_OK(hipMemsetAsync(h->pre_ctr, 0, qrw::kPreCtrWords * sizeof(unsigned), (hipStream_t)stream), "qrw_mpc_solve: counter reset");
     // a solve that a given-up queue left unfinished (never expected; qrw_mpc_get_stats reports it) must not leave the previous
     // call's numbers in the caller's buffer: NaN (all-ones bytes) until the finishing slice writes the result (~10 us per call)
@@ -756,7 +765,7 @@ extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] 
   if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   HIP_OK(hipDeviceSynchronize(), "sync");
-  HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * 10 * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
+  HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * qrw::kMpcProfItems * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
   return 0;
 }
 

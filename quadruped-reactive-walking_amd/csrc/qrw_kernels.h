@@ -38,6 +38,13 @@ enum MpcStateItem {
   kMpcStItems = 56
 };
 
+// diagnostic builds: doubles per instance in MpcArgs::prof (-DQRW_TRACE_RES: 20 x (primal ratio, dual ratio, rho) at the
+// adaptive-rho tests, scripts/gpu_res_trace.py)
+#ifdef QRW_TRACE_RES
+constexpr int kMpcProfItems = 64;
+#else
+constexpr int kMpcProfItems = 10;
+#endif
 struct MpcArgs {
   int B, N, N_gait;
   double dt;
@@ -56,7 +63,7 @@ struct MpcArgs {
   double* dua;
   int* rho_updates;
   const int* order;  // optional [B]: block i solves instance order[i] (longest-first scheduling)
-  double* prof;  // optional [B][10] phase cycle counters (diagnostic builds only)
+  double* prof;  // optional [B][kMpcProfItems] phase cycle counters / residual trace (diagnostic builds only)
   // sequences (qrw_mpc_solve_sequence): xref / fsteps / out hold seq_K call-major blocks, the queue hands tasks out
   int seq_K;
   int* queue;        // [seq_K * B]: the levels' FIFOs one after the other
@@ -69,11 +76,16 @@ struct MpcArgs {
   int pre_chunk;      // iterations per time slice (cut at the next multiple of 200)
   int pre_cmax;       // most slices one solve can need = workgroups per instance in the grid
   int pre_cap;        // slots in pre_queue = B * (pre_cmax - 1)
-  int* pre_queue;     // [pre_cap] parked instances in FIFO order, -1 = not filled yet
-  unsigned* pre_ctr;  // [kPreCtrWords] head / tail / finished / error / progress (mpc_kernel.hip)
+  int* pre_queue;     // [pre_levels][pre_cap] parked instances, one FIFO per priority level, -1 = not filled yet
+  unsigned* pre_ctr;  // [kPreCtrWords] tickets / parks / finished / error / progress / per-level head and tail (mpc_kernel.hip)
   int* pause_it;      // [B] iteration a solve was parked at, 0 = not parked
+  int pre_levels;     // 1: one FIFO (plain round robin); > 1: level 0 = solves parked after their first slice, levels 1.. by the
+                      // remaining iterations predicted from the residuals' decay (most first), pre_bin iterations per level
+  int pre_bin;
 };
-constexpr int kPreCtrWords = 48;
+constexpr int kPreMaxLevels = 9;
+constexpr int kPreLevelWord = 48;  // pre_ctr: head of level l at kPreLevelWord + 2 l, tail at + 2 l + 1
+constexpr int kPreCtrWords = kPreLevelWord + 2 * kPreMaxLevels + 14;
 int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
