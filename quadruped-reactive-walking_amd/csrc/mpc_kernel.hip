@@ -101,6 +101,9 @@ __device__ __forceinline__ void cone_apply_t(const double w[5], double mu, doubl
 
 // ---- step k <-> k+1 / k-1 neighbour values. One wavefront: ds_bpermute; two wavefronts: through LDS.
 // same[t] = value of lane (k+1, j); shifted[t] = value of lane (k+1, j-2) (only meaningful for j >= 2).
+// (Measured and dropped, round 3: leaving out the second barrier where another workgroup barrier separates this exchange from the
+// next one through the buffer anyway -- the force-elimination exchange of the ADMM loop -- is 1.9 % SLOWER at N = 32, A/B on one
+// box: 91.4 k against 93.2 k control steps/s; a second buffer for the other exchange costs the kernel 12-36 B of scratch.)
 template <int NW>
 __device__ __forceinline__ void nb_next(const double v[3], double same[3], double shifted[3], double* sE, int k, int j,
                                         int lane, bool has_next) {
@@ -114,7 +117,7 @@ __device__ __forceinline__ void nb_next(const double v[3], double same[3], doubl
     const int kn = has_next ? k + 1 : k;
 #pragma unroll
     for (int t = 0; t < 3; t++) { same[t] = sE[kn * 12 + 3 * j + t]; shifted[t] = sE[kn * 12 + 3 * ((j + 2) & 3) + t]; }
-    __syncthreads();
+    __syncthreads();  // (the schedule around it stays what it was with the barrier: the register file is full)
   }
 }
 // same[t] = value of lane (k-1, j); shifted[t] = value of lane (k-1, j+2) (only meaningful for j < 2).
@@ -1242,7 +1245,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           for (int c = 0; c < 12; c++) s_ += dr[c] * u[c];
           v[t] = s_;
         }
-        wg_sync();
+        // (no workgroup barrier: a quad reads and overwrites only its own step's slot, and the LDS executes a wavefront's
+        // operations in order -- the compiler alone must not move the stores above the loads)
+        asm volatile("" ::: "memory");
         if (act) {
 #pragma unroll
           for (int t = 0; t < 3; t++) L.sX[kx * 12 + 3 * j + t] = v[t];
