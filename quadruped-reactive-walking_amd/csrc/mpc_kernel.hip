@@ -515,7 +515,7 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // prediction at iteration 600 still misses the slow mode that takes over later in about 1 % of the solves, and one such solve
 // left for the end costs more than all the ordering gains); from the second park on its level is 1 + (levels - 2 -
 // predicted remaining / pre_bin), most remaining first, re-predicted at every park.  A workgroup takes from the lowest-numbered
-// level that has a solve: longest-remaining-first on 400-iteration bins, 1.03 x in the simulation (scripts/pre_priority_sim.py).
+// level that has a solve: longest-remaining-first on 200-iteration bins, 1.03 x in the simulation (scripts/pre_priority_sim.py).
 //   Queues: pre_queue[level][slot]; per level a head (next slot to take) and a tail (next slot to fill).  A taker first draws
 // a TICKET T and waits until more than T solves have been parked in total (`parks`): from then on a solve is there for it --
 // tickets are drawn by resident workgroups only, every ticket below `parks` belongs to a workgroup that takes exactly one

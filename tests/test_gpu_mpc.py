@@ -494,21 +494,27 @@ def test_sequence_on_a_masked_stream_beside_another_stream_group(synth_mod):
     other.close()
 
 
-@pytest.mark.parametrize("N,B,chunk,gaits", [(32, 1300, 600, ("walk", "trot", "bounding")), (32, 700, 200, ("trot", "bounding")),
-                                             (24, 900, 400, ("trot", "walk"))])
-def test_time_sliced_launch_is_independent_of_the_slicing(synth_mod, N, B, chunk, gaits, monkeypatch):
+@pytest.mark.parametrize("N,B,chunk,gaits,levels,lbin", [
+    (32, 1300, 600, ("walk", "trot", "bounding"), 9, 400), (32, 700, 200, ("trot", "bounding"), 9, 400),
+    (24, 900, 400, ("trot", "walk"), 9, 400), (32, 900, 400, ("walk", "trot", "bounding"), 1, 400),
+    (32, 900, 400, ("walk", "trot", "bounding"), 4, 100)])
+def test_time_sliced_launch_is_independent_of_the_slicing(synth_mod, N, B, chunk, gaits, levels, lbin, monkeypatch):
     """qrw_mpc_solve at N > 16 with more instances than resident slots time-slices the solves round robin inside the
     launch (slices of `chunk` iterations, parked solves resumed by later workgroups, mpc_kernel.hip PRE).  A resumed solve
     must be the uninterrupted one BIT FOR BIT: results, iteration counts, status, rho and the warm-start state left behind
     (checked through the following calls) are compared between slices of `chunk` iterations and slices of 3800 (the same
     kernel, where practically nothing is ever parked).  Against a handle with the slicing switched off -- a different
     instantiation of the kernel, whose floating-point contraction the compiler chooses on its own -- iteration counts and
-    status must be identical and the results equal to rounding (measured: identical at N = 32, <= 1e-9 at N = 24)."""
+    status must be identical and the results equal to rounding (measured: identical at N = 32, <= 1e-9 at N = 24).
+    Which parked solve a free workgroup takes next -- one FIFO (levels = 1) or the priority levels by predicted remaining
+    iterations (the default: 9 levels of 400 iterations; 4 levels of 100 here as a third shape) -- must not show in any word."""
     import torch
 
     import qrw_hip
 
     N_gait = max(20, N + 4)
+    monkeypatch.setenv("QRW_PREEMPT_LEVELS", str(levels))
+    monkeypatch.setenv("QRW_PREEMPT_BIN", str(lbin))
     sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, seed0=20300000 + N)
     monkeypatch.setenv("QRW_PREEMPT_CHUNK", "0")
     plain = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
