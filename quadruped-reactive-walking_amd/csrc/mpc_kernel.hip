@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const bool resumed = PRE && it_resume > 0;
   if constexpr (PRE) { if (tid < 8) L.sPre[tid] = 0.0; }
 #ifdef QRW_TRACE_RES
-  if (!resumed && a.prof && tid < kMpcProfItems) a.prof[(size_t)b * kMpcProfItems + tid] = 0.0;
+  if (!resumed && a.prof) for (int e = tid; e < kMpcProfItems; e += T) a.prof[(size_t)b * kMpcProfItems + e] = 0.0;
 #endif
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   const int N = a.N;
@@ -1384,6 +1384,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       pres = block_max<NW>(pres, L.sRed, wv, lane); nz = block_max<NW>(nz, L.sRed, wv, lane);
       nax = block_max<NW>(nax, L.sRed, wv, lane);
       pri_res = pres;
+#ifdef QRW_TRACE_RES
+      if (tid == 0 && a.prof) a.prof[(size_t)b * kMpcProfItems + 64 + (iter / 25 - 1)] = pres / (eps_abs + eps_rel * fmax(nz, nax));
+#endif
       last_np = fmax(nz, nax);
       const bool pri_ok = pri_res < eps_abs + eps_rel * last_np;
       // The dual residual is only needed to terminate (primal side passed), for the rho adaptation every 200

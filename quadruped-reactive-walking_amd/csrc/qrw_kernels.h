@@ -41,7 +41,7 @@ enum MpcStateItem {
 // diagnostic builds: doubles per instance in MpcArgs::prof (-DQRW_TRACE_RES: 20 x (primal ratio, dual ratio, rho) at the
 // adaptive-rho tests, scripts/gpu_res_trace.py)
 #ifdef QRW_TRACE_RES
-constexpr int kMpcProfItems = 64;
+constexpr int kMpcProfItems = 64 + 160;  // + the primal ratio at every termination check (every 25 iterations)
 #else
 constexpr int kMpcProfItems = 10;
 #endif

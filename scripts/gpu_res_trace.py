@@ -14,8 +14,9 @@ Ng = max(20, N + 4)
 sb = synth.SyntheticBatch(B, N, N_gait=Ng, gaits=gaits, n_seq=S + 1)
 g = qrw_hip.Batch(B, N, N_gait=Ng, T_gait=0.02 * N)
 its = np.zeros((S, B), dtype=np.int32)
-tr = np.zeros((S, B, 64), dtype=np.float32)
-buf = np.zeros((B, 64), dtype=np.float64)
+W = 64 + 160  # kMpcProfItems of the trace build: 20 x (primal ratio, dual ratio, rho) at the rho tests + the primal ratio at every check
+tr = np.zeros((S, B, W), dtype=np.float32)
+buf = np.zeros((B, W), dtype=np.float64)
 for s in range(S):
     d = sb.step(s)
     g.mpc_solve_host(d["xref"], d["fsteps"], s)
