@@ -65,7 +65,12 @@ const char *qrw_last_error(void);
  *   d_fsteps   [B][N_gait][12] row i = horizon step i, zero = swing / beyond horizon
  *   d_num_iter [B] int32 or NULL; if NULL num_iter_scalar applies to every instance.
  *              num_iter == 0 (re)creates the QP and cold-starts the solver (MPC.cpp:636-637)
- *   d_out      [B][24][N]     x_f_applied: rows 0-11 predicted states, 12-23 forces */
+ *   d_out      [B][24][N]     x_f_applied: rows 0-11 predicted states, 12-23 forces
+ * Scheduling inside the call (no reference counterpart; never visible in the results): instances are started longest first by
+ * a moving average of their previous iteration counts; at N > 16 with more instances than the device holds at a time, a
+ * workgroup runs at most 600 ADMM iterations of a solve, then parks it (bit-exact resume) and the parked solves are taken
+ * longest-predicted-remainder first, the prediction read off the decay of the residuals (d_out is pre-filled with NaN then;
+ * qrw_mpc_get_stats reports a queue that gave up, never expected).  Environment knobs: INTEGRATION.md. */
 int qrw_mpc_solve(qrw_handle h, const double *d_xref, const double *d_fsteps, const int32_t *d_num_iter,
                   int32_t num_iter_scalar, double *d_out, void *stream);
 /* same with host buffers (H2D, solve, D2H, synchronised) — used by the single-robot drop-in */
