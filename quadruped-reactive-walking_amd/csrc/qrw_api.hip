@@ -388,10 +388,10 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
     if (hipMalloc((void**)&h->seq_queue, need * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc queue");
     h->seq_queue_len = need;
   }
-  if (!h->seq_ctr) {
-    if (hipMalloc((void**)&h->seq_ctr, qrw::kSeqQctrWords * sizeof(unsigned)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc counters");
-    if (hipMalloc((void**)&h->seq_first, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc first tasks");
-    if (hipMalloc((void**)&h->seq_hot, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) return fail(-10, "qrw_mpc_solve_sequence: hipMalloc hot flags");
+  if (!h->seq_ctr || !h->seq_first || !h->seq_hot) {  // (each on its own: a call that failed half-way is retried from where it failed)
+    if (!h->seq_ctr && hipMalloc((void**)&h->seq_ctr, qrw::kSeqQctrWords * sizeof(unsigned)) != hipSuccess) { h->seq_ctr = nullptr; return fail(-10, "qrw_mpc_solve_sequence: hipMalloc counters"); }
+    if (!h->seq_first && hipMalloc((void**)&h->seq_first, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) { h->seq_first = nullptr; return fail(-10, "qrw_mpc_solve_sequence: hipMalloc first tasks"); }
+    if (!h->seq_hot && hipMalloc((void**)&h->seq_hot, (size_t)h->cfg.batch * sizeof(int)) != hipSuccess) { h->seq_hot = nullptr; return fail(-10, "qrw_mpc_solve_sequence: hipMalloc hot flags"); }
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, h->cfg.device), "hipGetDeviceProperties");
     // resident workgroups: one 512-register wavefront per SIMD (N <= 16: 4 workgroups per CU; N > 16: 2 of two wavefronts).
