@@ -120,6 +120,12 @@ int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double 
  * the device.  No reference counterpart (scheduling only; results do not depend on it).  Tests only. */
 int qrw_mpc_get_order(qrw_handle h, int32_t *h_order, float *h_ema, int32_t *has_order);
 
+/* Diagnostic: bookkeeping of the last time-sliced qrw_mpc_solve (N > 16 with more instances than resident slots; all zero
+ * otherwise): priority levels and slice length in use, solves parked into each level (level 0 = first parks), taker
+ * workgroups that drew a ticket, instances counted as finished.  No reference counterpart. */
+int qrw_mpc_get_slice_stats(qrw_handle h, int32_t *levels, int32_t *chunk, uint32_t *h_parks_per_level /* [9] */,
+                            uint32_t *h_takers, uint32_t *h_finished);
+
 /* Replaces wbc_controller.compute (scripts/QP_WBC.py:52-131) with everything it calls:
  * Solo12InvKin.refreshAndCompute (scripts/solo12InvKin.py:44-69), InvKin::refreshAndCompute
  * (src/InvKin.cpp:23-73), the Pinocchio crba/Jacobian/rnea calls (QP_WBC.py:89-116) and

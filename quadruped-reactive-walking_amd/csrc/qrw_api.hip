@@ -496,6 +496,25 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   return 0;
 }
 
+// Diagnostic: bookkeeping of the last time-sliced qrw_mpc_solve (N > 16, batch above the resident slots; zeros otherwise).
+extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* chunk, uint32_t* h_parks_per_level /* [9] */,
+                                       uint32_t* h_takers, uint32_t* h_finished) {
+  if (!h || !levels || !chunk || !h_parks_per_level || !h_takers || !h_finished) return fail(-1, "qrw_mpc_get_slice_stats: null argument");
+  DeviceScope dev_scope__(h->cfg.device);
+  *levels = h->pre_ctr ? h->pre_levels : 0;
+  *chunk = h->pre_ctr ? h->pre_chunk : 0;
+  for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = 0;
+  *h_takers = *h_finished = 0;
+  if (!h->pre_ctr) return 0;
+  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_slice_stats sync");
+  unsigned c[qrw::kPreCtrWords];
+  HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_get_slice_stats");
+  for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = c[qrw::kPreLevelWord + 2 * l + 1];
+  *h_takers = c[0];
+  *h_finished = c[32];
+  return 0;
+}
+
 extern "C" int qrw_mpc_get_order(qrw_handle h, int32_t* h_order, float* h_ema, int32_t* has_order) {
   if (!h || !has_order) return fail(-1, "qrw_mpc_get_order: null argument");
   DeviceScope dev_scope__(h->cfg.device);

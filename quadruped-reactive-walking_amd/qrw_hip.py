@@ -52,6 +52,7 @@ SIGNATURES = {
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_mpc_get_order": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "qrw_mpc_get_slice_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
     "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),
     "qrw_wbc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
@@ -536,6 +537,16 @@ class Batch:
         _check(self._lib.qrw_mpc_get_order(self._handle, order.ctypes.data_as(C.c_void_p), ema.ctypes.data_as(C.c_void_p),
                                            C.cast(C.byref(has), C.c_void_p)), "qrw_mpc_get_order")
         return (order, ema) if has.value else None
+
+    def mpc_slice_stats(self):
+        """Diagnostic: bookkeeping of the last time-sliced solve (N > 16, batch above the resident slots): priority levels and
+        slice length in use, solves parked into each level, taker workgroups that drew a ticket, finished instances."""
+        lv, ch, tk, fin = C.c_int32(0), C.c_int32(0), C.c_uint32(0), C.c_uint32(0)
+        parks = np.zeros(9, np.uint32)
+        _check(self._lib.qrw_mpc_get_slice_stats(self._handle, C.cast(C.byref(lv), _vp), C.cast(C.byref(ch), _vp),
+                                                 parks.ctypes.data_as(C.c_void_p), C.cast(C.byref(tk), _vp),
+                                                 C.cast(C.byref(fin), _vp)), "qrw_mpc_get_slice_stats")
+        return {"levels": lv.value, "chunk": ch.value, "parks_per_level": parks, "takers": tk.value, "finished": fin.value}
 
     def mpc_state(self, b=0):
         N = self.N

@@ -541,6 +541,35 @@ def test_time_sliced_launch_is_independent_of_the_slicing(synth_mod, N, B, chunk
     assert many > 0, "no solve needed more than two slices: the test does not exercise a resumed solve twice"
 
 
+def test_time_sliced_launch_bookkeeping(synth_mod, monkeypatch):
+    """The queue's own accounts after a time-sliced launch (qrw_mpc_get_slice_stats): every instance counted as finished,
+    exactly ceil(iterations / slice) - 1 parks per solve over all levels, of which the first parks (one per solve longer than
+    a slice) sit in level 0 and the later ones in the predicted-remainder levels -- more than one of them in use --, and at
+    least as many takers as parks (every parked solve found its taker)."""
+    import torch
+
+    import qrw_hip
+
+    N, B, chunk, N_gait = 32, 1100, 400, 36
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", str(chunk))
+    monkeypatch.setenv("QRW_PREEMPT_MIN_BATCH", "8")
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=("walk", "trot", "bounding"), seed0=20330000)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    dev = torch.device("cuda", 0)
+    for s in range(3):
+        d = sb.step(s)
+        eng.mpc_solve(torch.from_numpy(d["xref"]).to(dev), torch.from_numpy(d["fsteps"]).to(dev), s)
+        it = eng.mpc_stats()["iters"].astype(np.int64)
+        st = eng.mpc_slice_stats()
+        parks = st["parks_per_level"].astype(np.int64)
+        assert st["levels"] == 9 and st["chunk"] == chunk and st["finished"] == B
+        slices = -(-it // chunk)
+        assert parks.sum() == (slices - 1).sum(), (s, parks, (slices - 1).sum())
+        assert parks[0] == (it > chunk).sum(), (s, parks[0], (it > chunk).sum())
+        assert (parks[1:] > 0).sum() >= 3, parks
+        assert st["takers"] >= parks.sum()
+
+
 def test_time_sliced_launch_matches_the_oracle(oracle_mod, synth_mod, monkeypatch):
     """The time-sliced launch straight against the CPU oracle (slices of 200 iterations forced on a small batch): every
     instance takes the oracle's iteration count and status, results within 1e-4."""
