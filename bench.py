@@ -420,9 +420,16 @@ def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0):
         ms = np.array([a.elapsed_time(b) for a, b in ev])
         iters = it_dev.cpu().numpy().astype(np.float64)
         status = eng.mpc_stats()["status"]
+        sl = eng.mpc_slice_stats()  # (last timed launch; zeros where the launch is not time-sliced)
         eng.close()
         flops = iters.sum() * f_iter(N) + K * B * (f_fac(N) + F_ASM)
-        return {"value": B * K / el, "unit": "MPC solves/s" if mpc_only else "steps/s", "ms_per_step": 1e3 * el / K,
+        extra = {}
+        if sl["levels"]:
+            extra["time_slicing"] = {"slice_iterations": sl["chunk"], "priority_levels": sl["levels"],
+                                     "parks_per_level_last_launch": [int(v) for v in sl["parks_per_level"][:sl["levels"]]],
+                                     "what": "solves parked after a slice and taken longest-predicted-remainder first (DESIGN.md 4.1); "
+                                             "level 0 = first parks"}
+        return {**extra, "value": B * K / el, "unit": "MPC solves/s" if mpc_only else "steps/s", "ms_per_step": 1e3 * el / K,
                 "launch_ms_mean": float(ms.mean()), "mean_admm_iters": float(iters.mean()), "max_admm_iters": int(iters.max()),
                 "max_iter_exit_share": float((iters >= 4000).mean()),
                 "solved_share_last_step": float((status == 1).mean()),
