@@ -485,7 +485,7 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   if (h->pre_ctr) {  // a time-sliced launch whose queue gave up (never expected) left solves unfinished: say so, loudly
     unsigned c[qrw::kPreCtrWords];
     HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "D2H pre_ctr");
-    if (c[33] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
+    if (c[33] != 0) /* word 33: error (1, 3, 4: a taker gave up waiting; 2: a level's queue overran) */ return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
                                      "or overran its queue; results of that call are incomplete");
   }
   if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
@@ -509,6 +509,7 @@ extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* c
   HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_slice_stats sync");
   unsigned c[qrw::kPreCtrWords];
   HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_get_slice_stats");
+  // pre_ctr layout (mpc_kernel.hip, kPre*): word 0 tickets drawn by takers, 32 finished instances, kPreLevelWord + 2 l + 1 tail of level l
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = c[qrw::kPreLevelWord + 2 * l + 1];
   *h_takers = c[0];
   *h_finished = c[32];
