@@ -77,7 +77,7 @@ mpc_oracle *mpc_oracle_create(double dt_in, int n_steps_in, double T_gait_in, in
   o->xref = (double *)calloc(12 * (1 + N), sizeof(double));
   o->S_gait = (int *)calloc(12 * N, sizeof(int));
   o->x_f_applied = (double *)calloc(24 * N, sizeof(double));
-  o->gait = (int *)calloc(N_gait * 4, sizeof(int));
+  o->gait = (int *)calloc((N_gait + 1) * 4, sizeof(int)); /* + one all-zero row: construct_S / update_ML stop there when the table is full */
   o->mass = 2.50000279f; /* float literal promoted, :17 */
   o->mu = 0.9f;          /* :18 */
   o->offset_CoM[2] = -0.03; /* :21 */
@@ -124,14 +124,16 @@ static int row_is_zero_i(const int *row, int n) {
 /* MPC::construct_gait, MPC.cpp:686-701 */
 static void construct_gait(mpc_oracle *o, const double *fsteps) {
   int k = 0;
-  for (;;) {
+  /* (k < N_gait: with a table that has no all-zero row the reference reads and writes one row past its N_gait x 4 matrix;
+   * the restatement stops at the table's end, as the HIP kernel does) */
+  while (k < o->N_gait) {
     int zero = 1;
     for (int i = 0; i < 12; i++) if (fsteps[k * 12 + i] != 0.0) { zero = 0; break; }
     if (zero) break;
     for (int i = 0; i < 4; i++) o->gait[k * 4 + i] = (fsteps[k * 12 + i * 3] == 0.0) ? 0 : 1;
     k++;
   }
-  for (int i = 0; i < 4; i++) o->gait[k * 4 + i] = 0;
+  if (k < o->N_gait) for (int i = 0; i < 4; i++) o->gait[k * 4 + i] = 0;
 }
 
 /* MPC::construct_S, MPC.cpp:665-681 */

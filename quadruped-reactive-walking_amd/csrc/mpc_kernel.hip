@@ -524,9 +524,8 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // end of the launch, when the queues are empty).  No deadlock: a waiting taker waits for a park that a RUNNING slice makes; if
 // every resident workgroup waited there would be no parked solve left (each has its ticket's taker) and none running, i.e. all
 // have finished, which the takers see (`finished` == B) and leave.
-//   pre_ctr words: 0 tickets, 16 parks, 32 finished instances, 33 error, 34 progress, kPreLevelWord + 2 l / + 2 l + 1: head / tail of level l
-constexpr int kPreHead = 0, kPreTail = 16, kPreDone = 32, kPreErr = 33, kPreProgress = 34;
-static_assert(kPreProgress < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
+//   pre_ctr words: qrw_kernels.h (kPre*Word)
+constexpr int kPreHead = kPreTicketWord, kPreTail = kPreParksWord, kPreDone = kPreDoneWord, kPreErr = kPreErrWord, kPreProgress = kPreProgressWord;
 template <int NW>
 __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
   int task = -1;

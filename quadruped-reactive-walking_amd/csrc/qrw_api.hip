@@ -13,6 +13,7 @@
 
 #include "../../include/qrw_hip.h"
 #include "../../include/qrw_solo12_model.h"
+#include "kat_table.h"
 #include "qrw_kernels.h"
 
 namespace {
@@ -125,34 +126,52 @@ static void base_inertia_diag(double Y[6]) {
 }
 
 
-// Known-answer check of THIS build of mpc_solve_kernel, run once per process and device by qrw_create (and by
-// qrw_selftest_sweeps).  Why it exists: the kernel lives at the edge of the register file, and one combination of compiler
-// options has produced a library in which every solve diverges; the parity tests catch that, a deployment
-// that only rebuilds the library would not.  Case: the reference's four-stance immobile scenario (scripts/test_mpc.py:
-// 54-62: height 0.2447..., feet at (+-0.195, +-0.147)), first MPC call, N = 16.  Expected values recorded from the CPU
-// restatement (oracle/, 2026-10): 350 ADMM iterations (one rho adaptation at iteration 200), rho 1.03905792582975e-3,
-// four equal vertical forces summing to 24.5347812847 N (m g = 24.525 N), horizontal forces zero.
-struct KatResult { int iters = -1, status = 0; double err = 0.0, rho = 0.0; };
-static int mpc_known_answer_check(KatResult* res) {
-  constexpr int N = 16, Ng = 20, T = 64;
-  double hx[12 * (N + 1)] = {0}, hf[Ng * 12] = {0}, hout[24 * N];
+// Known-answer check of THIS build of mpc_solve_kernel, run by qrw_create once per process, device and INSTANTIATION the
+// handle will launch (and by qrw_selftest_sweeps for all of them).  Why it exists: the kernel lives at the edge of the register
+// file, and one combination of compiler options has produced a library in which every solve diverges; the parity
+// tests catch that, a deployment that only rebuilds the library would not -- and each of the ten instantiations is its own piece
+// of generated code (the N = 32 forms sit closest to the register limit).  Case: the reference's four-stance immobile scenario
+// (scripts/test_mpc.py:54-62: height 0.2447..., feet at (+-0.195, +-0.147)), first MPC call, at the handle's own horizon N.
+// Expected values per N: kat_table.h, generated from the CPU restatement by scripts/make_kat_table.py (N = 16: 350 ADMM
+// iterations with one rho adaptation at iteration 200, rho 1.03905792582975e-3, four equal vertical forces summing to
+// 24.5347812847 N against m g = 24.525 N, horizontal forces zero; N = 32: 375 iterations).
+//   mode kKatPlain:    mpc_launch                (<1,true> N = 16, <1,false> N < 16, <2,true> N = 32, <2,false> 16 < N < 32)
+//   mode kKatSliced:   mpc_preemptive_launch     (N > 16: the solve is cut after 200 iterations, parked, taken from the queue by
+//                                                 another workgroup and finished -- the time-sliced form config 4 runs by default)
+//   mode kKatSequence: mpc_sequence_launch, K = 1 (the SEQ instantiations of qrw_mpc_solve_sequence)
+enum KatMode { kKatPlain = 0, kKatSliced = 1, kKatSequence = 2, kKatModes = 3 };
+static const char* const kKatModeName[kKatModes] = {"one launch per call", "time-sliced launch", "sequence launch"};
+struct KatResult { int iters = -1, status = 0, want_iters = 0; double err = 0.0, rho = 0.0, want_rho = 0.0; };
+static int mpc_known_answer_check(int N, int mode, KatResult* res) {
+  if (N < 1 || N > qrw::kMpcMaxN || mode < 0 || mode >= kKatModes || (mode == kKatSliced && N <= 16)) return -13;
+  const int Ng = N > 20 ? N : 20, T = qrw::mpc_threads(N);
+  const qrw::KatRow& want = qrw::kKatTable[N];
+  std::vector<double> hx(12 * (N + 1), 0.0), hf((size_t)Ng * 12, 0.0), hout(24 * N);
   for (int c = 0; c <= N; c++) hx[2 * (N + 1) + c] = 0.24474949993103629;
   const double feet[12] = {0.195, 0.147, 0., 0.195, -0.147, 0., -0.195, 0.147, 0., -0.195, -0.147, 0.};
   for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) hf[k * 12 + i] = feet[i];
   struct Buf { void* p = nullptr; ~Buf() { if (p) hipFree(p); } };
-  Buf bx, bf, bo, bst, bg, bi, bd;
-  const size_t n_int = 8, n_dbl = 16;
-  if (hipMalloc(&bx.p, sizeof(hx)) != hipSuccess || hipMalloc(&bf.p, sizeof(hf)) != hipSuccess || hipMalloc(&bo.p, sizeof(hout)) != hipSuccess ||
-      hipMalloc(&bst.p, qrw::kMpcStItems * T * sizeof(double)) != hipSuccess || hipMalloc(&bg.p, Ng * 4 * sizeof(int)) != hipSuccess ||
-      hipMalloc(&bi.p, n_int * sizeof(int)) != hipSuccess || hipMalloc(&bd.p, n_dbl * sizeof(double)) != hipSuccess)
+  Buf bx, bf, bo, bst, bg, bi, bd, bq, bc;
+  const size_t n_int = 16, n_dbl = 16;
+  constexpr int kChunk = 200, kCmax = 4000 / kChunk, kLevels = 2;  // sliced: one parked solve at a time, 19 queue-fed workgroups
+  const size_t q_ints = (size_t)kLevels * (kCmax - 1) + 8;         // (also covers the sequence launch's one-task queue)
+  const size_t c_words = qrw::kPreCtrWords > qrw::kSeqQctrWords ? qrw::kPreCtrWords : qrw::kSeqQctrWords;
+  if (hipMalloc(&bx.p, hx.size() * sizeof(double)) != hipSuccess || hipMalloc(&bf.p, hf.size() * sizeof(double)) != hipSuccess ||
+      hipMalloc(&bo.p, hout.size() * sizeof(double)) != hipSuccess || hipMalloc(&bst.p, (size_t)qrw::kMpcStItems * T * sizeof(double)) != hipSuccess ||
+      hipMalloc(&bg.p, (size_t)Ng * 4 * sizeof(int)) != hipSuccess || hipMalloc(&bi.p, n_int * sizeof(int)) != hipSuccess ||
+      hipMalloc(&bd.p, n_dbl * sizeof(double)) != hipSuccess || hipMalloc(&bq.p, q_ints * sizeof(int)) != hipSuccess ||
+      hipMalloc(&bc.p, c_words * sizeof(unsigned)) != hipSuccess)
     return -10;
   // blocking copies / memsets on the null stream of pageable host memory: complete when they return
-  hipMemcpy(bx.p, hx, sizeof(hx), hipMemcpyHostToDevice);
-  hipMemcpy(bf.p, hf, sizeof(hf), hipMemcpyHostToDevice);
-  hipMemset(bst.p, 0, qrw::kMpcStItems * T * sizeof(double));
-  hipMemset(bg.p, 0, Ng * 4 * sizeof(int));
+  hipMemcpy(bx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice);
+  hipMemcpy(bf.p, hf.data(), hf.size() * sizeof(double), hipMemcpyHostToDevice);
+  hipMemset(bo.p, 0xFF, hout.size() * sizeof(double));
+  hipMemset(bst.p, 0, (size_t)qrw::kMpcStItems * T * sizeof(double));
+  hipMemset(bg.p, 0, (size_t)Ng * 4 * sizeof(int));
   hipMemset(bi.p, 0, n_int * sizeof(int));
   hipMemset(bd.p, 0, n_dbl * sizeof(double));
+  hipMemset(bq.p, 0xFF, q_ints * sizeof(int));
+  hipMemset(bc.p, 0, c_words * sizeof(unsigned));
   hipStreamSynchronize(nullptr);
   qrw::MpcArgs a;
   memset(&a, 0, sizeof(a));
@@ -165,11 +184,24 @@ static int mpc_known_answer_check(KatResult* res) {
   // a private non-blocking stream: the check neither waits for nor stalls the work other streams of the process have queued
   struct Stream { hipStream_t s = nullptr; ~Stream() { if (s) hipStreamDestroy(s); } } st;
   if (hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) != hipSuccess) return -10;
-  if (qrw::mpc_launch(a, st.s) != 0) return -11;
-  int hi[n_int]; double hd[n_dbl];
+  int lrc;
+  if (mode == kKatSliced) {
+    a.pre_chunk = kChunk; a.pre_cmax = kCmax; a.pre_cap = kCmax - 1; a.pre_levels = kLevels; a.pre_bin = 200;
+    a.pre_queue = (int*)bq.p; a.pre_ctr = (unsigned*)bc.p; a.pause_it = ip + 8;
+    lrc = qrw::mpc_preemptive_launch(a, st.s);
+  } else if (mode == kKatSequence) {
+    a.seq_K = 1; a.queue = (int*)bq.p; a.qctr = (unsigned*)bc.p; a.seq_hot = ip + 9; a.seq_first = ip + 10; a.seq_groups = 1; a.seq_iters = ip + 11;
+    lrc = qrw::mpc_sequence_launch(a, st.s);
+  } else {
+    lrc = qrw::mpc_launch(a, st.s);
+  }
+  if (lrc != 0) return -11;
+  int hi[n_int]; double hd[n_dbl]; unsigned hc[8] = {0};
   hipMemcpyAsync(hi, bi.p, sizeof(hi), hipMemcpyDeviceToHost, st.s);
   hipMemcpyAsync(hd, bd.p, sizeof(hd), hipMemcpyDeviceToHost, st.s);
-  hipMemcpyAsync(hout, bo.p, sizeof(hout), hipMemcpyDeviceToHost, st.s);
+  hipMemcpyAsync(hout.data(), bo.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st.s);
+  if (mode == kKatSliced) hipMemcpyAsync(hc, (unsigned*)bc.p + qrw::kPreErrWord, sizeof(unsigned), hipMemcpyDeviceToHost, st.s);
+  if (mode == kKatSequence) hipMemcpyAsync(hc, (unsigned*)bc.p + qrw::kSeqErrWord, sizeof(unsigned), hipMemcpyDeviceToHost, st.s);
   if (hipStreamSynchronize(st.s) != hipSuccess) return -12;
   double err = 0.0, fz = 0.0;
   for (int j = 0; j < 4; j++) {
@@ -177,39 +209,54 @@ static int mpc_known_answer_check(KatResult* res) {
     err = fmax(err, fabs(hout[(12 + 3 * j + 2) * N] - hout[14 * N]));      // equal vertical forces
     err = fmax(err, fabs(hout[(12 + 3 * j) * N]) + fabs(hout[(12 + 3 * j + 1) * N]));  // no horizontal force
   }
-  err = fmax(err, fabs(fz - 24.534781284726584));
-  err = fmax(err, fabs(hd[0] / 1.0390579258297492e-3 - 1.0));
+  err = fmax(err, fabs(fz - want.fz));
+  err = fmax(err, fabs(hd[0] / want.rho - 1.0));
+  if (hc[0] != 0) err = 1e300;       // the queue of the time-sliced / sequence launch gave up
   if (!(err == err)) err = 1e300;  // NaN
-  if (res) { res->iters = hi[1]; res->status = hi[2]; res->err = err; res->rho = hd[0]; }
+  if (res) { res->iters = hi[1]; res->status = hi[2]; res->err = err; res->rho = hd[0]; res->want_iters = want.iters; res->want_rho = want.rho; }
   // The pass criterion is the ANSWER (status solved, forces and rho to 1e-8).  The iteration count is reported, and
-  // only checked loosely: 350 with the shipped toolchain; a legitimate compiler change may move a borderline termination
-  // test by one check interval (25), a miscompiled kernel diverges (status != solved) or lands far away.
-  return (hi[2] == qrw::kStatusSolved && err < 1e-8 && hi[1] >= 300 && hi[1] <= 400) ? 0 : 1;
+  // only checked loosely: the table's value with the shipped toolchain; a legitimate compiler change may move a borderline
+  // termination test by one check interval (25), a miscompiled kernel diverges (status != solved) or lands far away.
+  return (hi[2] == qrw::kStatusSolved && err < 1e-8 && hi[1] >= want.iters - 50 && hi[1] <= want.iters + 50) ? 0 : 1;
 }
-// per device: 0 not run, 1 passed, -1 failed; guarded by a mutex (qrw_create may be called from several threads)
+// per device, horizon and launch form: 0 not run, 1 passed, -1 failed; guarded by a mutex (qrw_create may be called from several threads)
 static std::mutex g_kat_mutex;
-static int g_kat_state[64] = {0};
-static KatResult g_kat_result[64];
-static int mpc_known_answer_once(int device) {
-  if (device < 0 || device >= 64) return 0;
+static signed char g_kat_state[64][qrw::kMpcMaxN + 1][kKatModes] = {};
+static KatResult g_kat_last;  // result of the most recent check (read under the mutex by the caller that ran it)
+static int mpc_known_answer_once(int device, int N, int mode, KatResult* out) {
+  if (device < 0 || device >= 64 || N < 1 || N > qrw::kMpcMaxN) return 0;
   std::lock_guard<std::mutex> lock(g_kat_mutex);
-  if (g_kat_state[device] == 0 && qrw::mpc_build_is_timing_experiment()) {
+  signed char& state = g_kat_state[device][N][mode];
+  if (state == 0 && qrw::mpc_build_is_timing_experiment()) {
     fprintf(stderr, "libqrw_hip: TIMING-EXPERIMENT BUILD (wrong results by construction), self-test skipped\n");
-    g_kat_state[device] = 1;
+    state = 1;
   }
-  if (g_kat_state[device] == 0) {
+  if (state == 0) {
     const char* skip = getenv("QRW_SKIP_SELFTEST");  // escape hatch (e.g. bring-up on a new toolchain): say so, loudly
     if (skip && skip[0] == '1') {
       fprintf(stderr, "libqrw_hip: QRW_SKIP_SELFTEST=1, the known-answer self-test of mpc_solve_kernel is SKIPPED\n");
-      g_kat_state[device] = 1;
+      state = 1;
     } else {
-      const int rc = mpc_known_answer_check(&g_kat_result[device]);
-      if (rc < 0) g_kat_result[device].status = rc;
-      g_kat_state[device] = (rc == 0) ? 1 : -1;
+      const int rc = mpc_known_answer_check(N, mode, &g_kat_last);
+      if (rc < 0) g_kat_last.status = rc;
+      state = (rc == 0) ? 1 : -1;
     }
   }
-  return g_kat_state[device] == 1 ? 0 : 1;
+  if (out) *out = g_kat_last;
+  return state == 1 ? 0 : 1;
 }
+static int kat_fail(const char* who, int N, int mode, const KatResult& r) {
+  char msg[640];
+  snprintf(msg, sizeof(msg),
+           "%s: the known-answer self-test of mpc_solve_kernel failed on this device for horizon N = %d, %s (got %d ADMM iterations, "
+           "status %d, rho %.10g, error %.3g; expected %d, solved, %.10g, < 1e-8): this build of libqrw_hip.so computes wrong results "
+           "(a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild with the Makefile's flags "
+           "(QRW_SKIP_SELFTEST=1 skips this check)", who, N, kKatModeName[mode], r.iters, r.status, r.rho, r.err, r.want_iters, r.want_rho);
+  return fail(-20, msg);
+}
+
+// the launch form qrw_mpc_solve uses for this handle (decided once, at creation)
+static bool mpc_time_sliced(const qrw_handle_s* h) { return h->pre_chunk > 0 && h->cfg.batch > h->pre_min_batch && h->pre_cmax > 1; }
 
 extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   if (!cfg || !out) return fail(-1, "qrw_create: null argument");
@@ -222,16 +269,6 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
     return fail(-2, "qrw_create: no HIP device (this library has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(-2, "qrw_create: bad device ordinal");
   DeviceScope dev_scope__(cfg->device);
-  if (mpc_known_answer_once(cfg->device) != 0) {
-    const KatResult& r = g_kat_result[cfg->device];
-    char msg[512];
-    snprintf(msg, sizeof(msg),
-             "qrw_create: the known-answer self-test of mpc_solve_kernel failed on this device (got %d ADMM iterations, status %d, "
-             "rho %.10g, error %.3g; expected 350, solved, 1.0390579258e-3, < 1e-8): this build of libqrw_hip.so computes wrong results "
-             "(a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild with the Makefile's flags "
-             "(QRW_SKIP_SELFTEST=1 skips this check)", r.iters, r.status, r.rho, r.err);
-    return fail(-20, msg);
-  }
   qrw_handle h = new qrw_handle_s();
   h->cfg = *cfg;
   const size_t B = (size_t)cfg->batch;
@@ -284,6 +321,14 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
       ALLOC(h->pre_queue, (size_t)h->pre_levels * B * (size_t)(h->pre_cmax > 1 ? h->pre_cmax - 1 : 1) * sizeof(int));
     }
   }
+  {  // known answer through the instantiation of mpc_solve_kernel this handle's qrw_mpc_solve will launch
+    const int mode = mpc_time_sliced(h) ? kKatSliced : kKatPlain;
+    KatResult r;
+    if (mpc_known_answer_once(cfg->device, N, mode, &r) != 0) {
+      qrw_destroy(h);
+      return kat_fail("qrw_create", N, mode, r);
+    }
+  }
   ALLOC(h->wbc_st, B * qrw::kWbcStItems * sizeof(double));
   ALLOC(h->wbc_iters, B * sizeof(int));
   ALLOC(h->wbc_status, B * sizeof(int));
@@ -333,7 +378,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
   a.rho_updates = h->mpc_rho_updates;
   a.prof = h->mpc_prof;
   a.order = h->mpc_have_order ? h->mpc_order : nullptr;
-  if (h->pre_chunk > 0 && h->cfg.batch > h->pre_min_batch && h->pre_cmax > 1) {
+  if (mpc_time_sliced(h)) {
     // more instances than resident slots at N > 16: the solves are time-sliced round robin inside the launch (same results)
     a.pre_chunk = h->pre_chunk; a.pre_cmax = h->pre_cmax; a.pre_cap = h->cfg.batch * (h->pre_cmax - 1);
     a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
@@ -378,6 +423,10 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
                                       double* d_out, int32_t* d_iters, void* stream) {
   if (!h || !d_xref || !d_fsteps || !d_out || K < 1) return fail(-1, "qrw_mpc_solve_sequence: bad argument");
   DeviceScope dev_scope__(h->cfg.device);
+  {  // the SEQ instantiation's known answer, once per process, device and horizon
+    KatResult r;
+    if (mpc_known_answer_once(h->cfg.device, h->cfg.n_steps, kKatSequence, &r) != 0) return kat_fail("qrw_mpc_solve_sequence", h->cfg.n_steps, kKatSequence, r);
+  }
   const size_t need = (size_t)K * (size_t)h->cfg.batch;
   if (need > (size_t)0x7fffffff) return fail(-1, "qrw_mpc_solve_sequence: K * batch too large");
   if (need > h->seq_queue_len) {  // grown on demand (first call / longer sequence), never on a steady-state call
@@ -485,7 +534,7 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   if (h->pre_ctr) {  // a time-sliced launch whose queue gave up (never expected) left solves unfinished: say so, loudly
     unsigned c[qrw::kPreCtrWords];
     HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "D2H pre_ctr");
-    if (c[33] != 0) /* word 33: error (1, 3, 4: a taker gave up waiting; 2: a level's queue overran) */ return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
+    if (c[qrw::kPreErrWord] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
                                      "or overran its queue; results of that call are incomplete");
   }
   if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
@@ -509,10 +558,9 @@ extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* c
   HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_slice_stats sync");
   unsigned c[qrw::kPreCtrWords];
   HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_get_slice_stats");
-  // pre_ctr layout (mpc_kernel.hip, kPre*): word 0 tickets drawn by takers, 32 finished instances, kPreLevelWord + 2 l + 1 tail of level l
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = c[qrw::kPreLevelWord + 2 * l + 1];
-  *h_takers = c[0];
-  *h_finished = c[32];
+  *h_takers = c[qrw::kPreTicketWord];
+  *h_finished = c[qrw::kPreDoneWord];
   return 0;
 }
 
@@ -770,13 +818,20 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
     return fail(3, msg);
   }
   if (max_err && derr > *max_err) *max_err = derr;
-  KatResult kat;
-  const int krc = mpc_known_answer_check(&kat);  // the whole solve, not only its sweeps
-  if (krc != 0) {
-    char msg[256];
-    snprintf(msg, sizeof(msg), "qrw_selftest_sweeps: known-answer MPC solve failed (rc %d: %d iterations, status %d, rho %.10g, error %.3g)",
-             krc, kat.iters, kat.status, kat.rho, kat.err);
-    return fail(2, msg);
+  // the whole solve, not only its sweeps: every instantiation of mpc_solve_kernel (compile-time and runtime horizon, one and two
+  // wavefronts, one launch per call / time-sliced / sequence)
+  static const int kat_cases[][2] = {{16, kKatPlain}, {12, kKatPlain}, {32, kKatPlain}, {24, kKatPlain}, {32, kKatSliced}, {24, kKatSliced},
+                                     {16, kKatSequence}, {12, kKatSequence}, {32, kKatSequence}, {24, kKatSequence}};
+  for (const auto& kc : kat_cases) {
+    KatResult kat;
+    const int krc = mpc_known_answer_check(kc[0], kc[1], &kat);
+    if (krc != 0) {
+      char msg[320];
+      snprintf(msg, sizeof(msg), "qrw_selftest_sweeps: known-answer MPC solve failed for N = %d, %s (rc %d: %d iterations, status %d, rho %.10g, "
+               "error %.3g; expected %d iterations, rho %.10g)", kc[0], kKatModeName[kc[1]], krc, kat.iters, kat.status, kat.rho, kat.err,
+               kat.want_iters, kat.want_rho);
+      return fail(2, msg);
+    }
   }
   return 0;
 }

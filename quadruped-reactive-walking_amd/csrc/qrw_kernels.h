@@ -72,7 +72,8 @@ struct MpcArgs {
   int* seq_first;    // [B] call-0 tasks dealt by workgroup index
   int seq_groups;    // workgroups resident at a time = call-0 tasks dealt by index
   int* seq_iters;    // optional [seq_K][B]
-  // preemptive launch (mpc_preemptive_launch): round-robin time slices of pre_chunk iterations, parked solves in one FIFO
+  // preemptive launch (mpc_preemptive_launch): time slices of pre_chunk iterations; parked solves wait in pre_levels FIFOs
+  // (level 0: parked after the first slice; 1..: by predicted remaining iterations, most first)
   int pre_chunk;      // iterations per time slice (cut at the next multiple of 200)
   int pre_cmax;       // most slices one solve can need = workgroups per instance in the grid
   int pre_cap;        // slots in pre_queue = B * (pre_cmax - 1)
@@ -84,8 +85,13 @@ struct MpcArgs {
   int pre_bin;
 };
 constexpr int kPreMaxLevels = 9;
-constexpr int kPreLevelWord = 48;  // pre_ctr: head of level l at kPreLevelWord + 2 l, tail at + 2 l + 1
+// pre_ctr words (one layout for the kernel, mpc_kernel.hip, and the host readers, qrw_api.hip): tickets drawn by takers, solves
+// parked in total, finished instances, error (1, 3, 4: a taker gave up waiting; 2: a level's queue overran), progress (chunks
+// ended: the give-up clock restarts on it); head of level l at kPreLevelWord + 2 l, its tail at + 2 l + 1
+constexpr int kPreTicketWord = 0, kPreParksWord = 16, kPreDoneWord = 32, kPreErrWord = 33, kPreProgressWord = 34;
+constexpr int kPreLevelWord = 48;
 constexpr int kPreCtrWords = kPreLevelWord + 2 * kPreMaxLevels + 14;
+static_assert(kPreProgressWord < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
 int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);

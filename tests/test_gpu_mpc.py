@@ -507,7 +507,7 @@ def test_time_sliced_launch_is_independent_of_the_slicing(synth_mod, N, B, chunk
     instantiation of the kernel, whose floating-point contraction the compiler chooses on its own -- iteration counts and
     status must be identical and the results equal to rounding (measured: identical at N = 32, <= 1e-9 at N = 24).
     Which parked solve a free workgroup takes next -- one FIFO (levels = 1) or the priority levels by predicted remaining
-    iterations (the default: 9 levels of 400 iterations; 4 levels of 100 here as a third shape) -- must not show in any word."""
+    iterations (the default: 9 levels, bins of 200 iterations; 4 levels of 100 here as a third shape) -- must not show in any word."""
     import torch
 
     import qrw_hip
