@@ -69,8 +69,13 @@ const char *qrw_last_error(void);
  * Scheduling inside the call (no reference counterpart; never visible in the results): instances are started longest first by
  * a moving average of their previous iteration counts; at N > 16 with more instances than the device holds at a time, a
  * workgroup runs at most 600 ADMM iterations of a solve, then parks it (bit-exact resume) and the parked solves are taken
- * longest-predicted-remainder first, the prediction read off the decay of the residuals (d_out is pre-filled with NaN then;
- * qrw_mpc_get_stats reports a queue that gave up, never expected).  Environment knobs: INTEGRATION.md. */
+ * longest-predicted-remainder first, the prediction read off the decay of the residuals.  d_out is pre-filled with NaN then:
+ * should the launch's queue ever give up (a workgroup waits 2 s for a parked solve without any slice of the launch ending --
+ * never expected; it rests on workgroups of one launch starting in index order), the unfinished instances keep NaN, the kernel
+ * leaves a code in a host-mapped word, and THE NEXT qrw_mpc_solve of the handle returns -12 once, without launching (no device
+ * sync involved; qrw_mpc_get_stats reports it as well).  The call after that runs normally and starts the unfinished instances
+ * cold (zero x, z, y, rho 0.1: what OSQP's store_solution leaves after a failed solve).  NaN forces stop the robot through the
+ * controller's fourth error code (qrw_controller_result).  Environment knobs: INTEGRATION.md. */
 int qrw_mpc_solve(qrw_handle h, const double *d_xref, const double *d_fsteps, const int32_t *d_num_iter,
                   int32_t num_iter_scalar, double *d_out, void *stream);
 /* same with host buffers (H2D, solve, D2H, synchronised) — used by the single-robot drop-in */
@@ -113,6 +118,11 @@ int qrw_mpc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double 
  * y[44N] and of the last solve's scaling D[24N], E[44N], c (any may be NULL). Tests only. */
 int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double *h_y, double *h_D, double *h_E,
                       double *h_c);
+
+/* Tests only: leave every instance of a time-sliced handle (N > 16, batch above the resident slots) as a launch whose queue
+ * gave up would -- parked at iteration `parked_at`, the warm-start slots holding values that are not OSQP's iterates -- so that
+ * the cold restart of the next qrw_mpc_solve can be checked without provoking a give-up.  -1 on other handles. */
+int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at);
 
 /* Diagnostic: the block order the NEXT qrw_mpc_solve will use (h_order[i] = instance solved by workgroup i: a
  * permutation of 0..B-1, longest predicted solve first) and the moving average of iteration counts it was sorted by
@@ -237,7 +247,9 @@ int qrw_controller_wbc_inputs(qrw_handle h, const double *d_x_f_mpc, const doubl
                               double *d_feet_cmd, void *stream);
 /* Result + security_check (scripts/Controller.py:306-310,341-365): d_tau_ff [B][12], d_qdes [B][19], d_vdes [B][18],
  * d_q_filt [B][19], d_v_secu [B][12] -> d_result [B][5][12] = P, D, q_des, v_des, tau_ff (0.8 x), d_error_flag [B]
- * int32 (0 ok, 1 joint position, 2 joint velocity, 3 torque; sticky, may be NULL). */
+ * int32 (0 ok, 1 joint position, 2 joint velocity, 3 torque: the reference's three codes; 4: a non-finite tau_ff / q_des /
+ * v_des -- NOT in the reference, whose `> limit` comparisons are blind to NaN and would pass it to the motors; sticky, may be
+ * NULL).  Any code sets the reference's security output (P = 0, D = 0.1, zero targets and torques). */
 int qrw_controller_result(qrw_handle h, const double *d_tau_ff, const double *d_qdes, const double *d_vdes,
                           const double *d_q_filt, const double *d_v_secu, double *d_result, int32_t *d_error_flag,
                           void *stream);

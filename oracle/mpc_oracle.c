@@ -429,6 +429,7 @@ void mpc_oracle_get_gait(const mpc_oracle *o, double *out) {
 void mpc_oracle_get_Sgait(const mpc_oracle *o, double *out) {
   for (int i = 0; i < 12 * o->n_steps; i++) out[i] = (double)o->S_gait[i];
 }
+int mpc_oracle_restart(mpc_oracle *o, double rho) { return o->work ? oq_restart(o->work, rho) : -1; }
 int mpc_oracle_iter(const mpc_oracle *o) { return o->work ? oq_info_iter(o->work) : -1; }
 int mpc_oracle_status(const mpc_oracle *o) { return o->work ? oq_info_status(o->work) : OQ_UNSOLVED; }
 double mpc_oracle_rho(const mpc_oracle *o) { return o->work ? oq_info_rho(o->work) : 0.0; }

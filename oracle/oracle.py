@@ -57,6 +57,7 @@ def load(fast=False):
         "mpc_oracle_get_latest_result": (None, [vp, _dp]),
         "mpc_oracle_get_gait": (None, [vp, _dp]),
         "mpc_oracle_get_Sgait": (None, [vp, _dp]),
+        "mpc_oracle_restart": (C.c_int, [vp, C.c_double]),
         "mpc_oracle_iter": (C.c_int, [vp]),
         "mpc_oracle_status": (C.c_int, [vp]),
         "mpc_oracle_rho": (C.c_double, [vp]),
@@ -131,6 +132,11 @@ class MPC:
         xref = _arr(xref_in, (12, self.n_steps + 1))
         fsteps = _arr(fsteps_in, (self.N_gait, 12))
         return self._lib.mpc_oracle_run(self._h, int(num_iter), _ptr(xref), _ptr(fsteps))
+
+    def cold_start(self, rho=0.1):
+        """Test hook (no reference counterpart): osqp_update_rho(rho) + cold start of the workspace, what restarts a solver
+        whose last solve was abandoned half-way (the HIP path's aborted time-sliced launch)."""
+        return self._lib.mpc_oracle_restart(self._h, float(rho))
 
     def get_latest_result(self):
         out = np.zeros((24, self.n_steps))

@@ -912,6 +912,14 @@ int oq_solve(oq_work *w) {
 
 const double *oq_solution_x(const oq_work *w) { return w->sol_x; }
 const double *oq_solution_y(const oq_work *w) { return w->sol_y; }
+/* test hook: what an integrator does to restart a workspace whose last solve was abandoned half-way -- osqp_update_rho(work,
+ * rho) followed by a cold start (x = z = y = 0, auxil.c cold_start) */
+int oq_restart(oq_work *w, double rho) {
+  int rc = update_rho(w, rho);
+  cold_start(w);
+  return rc;
+}
+
 int oq_info_iter(const oq_work *w) { return w->iter; }
 int oq_info_status(const oq_work *w) { return w->status; }
 double oq_info_pri_res(const oq_work *w) { return w->pri_res; }

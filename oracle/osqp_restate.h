@@ -77,6 +77,7 @@ int oq_update_bounds(oq_work *w, const double *l_new, const double *u_new);
 int oq_update_lower_bound(oq_work *w, const double *l_new);
 int oq_update_upper_bound(oq_work *w, const double *u_new);
 int oq_solve(oq_work *w);
+int oq_restart(oq_work *w, double rho);                     /* osqp_update_rho + cold start (tests of the aborted-launch path) */
 
 /* results / introspection */
 const double *oq_solution_x(const oq_work *w);

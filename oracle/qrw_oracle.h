@@ -43,6 +43,7 @@ void mpc_oracle_get_latest_result(const mpc_oracle *o, double *out_24xN);       
 void mpc_oracle_get_gait(const mpc_oracle *o, double *out_Ngaitx4);                       /* :770 */
 void mpc_oracle_get_Sgait(const mpc_oracle *o, double *out_12N);                          /* :776 */
 /* introspection for tests */
+int mpc_oracle_restart(mpc_oracle *o, double rho); /* osqp_update_rho + cold start of the MPC's workspace (test hook) */
 int mpc_oracle_iter(const mpc_oracle *o);
 int mpc_oracle_status(const mpc_oracle *o);
 double mpc_oracle_rho(const mpc_oracle *o);

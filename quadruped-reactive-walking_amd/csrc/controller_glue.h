@@ -194,12 +194,17 @@ __device__ __forceinline__ void result(const ControllerArgs& a, int b) {
   if (err == 0) {  // the WBC ran this iteration: keep its references for the next one (Controller.py:282,287)
     for (int i = 0; i < 12; i++) { s(cQDES + i) = qd[7 + i]; s(cVDES + i) = vd[6 + i]; }
     const double qsec[3] = {M_PI * 0.4, M_PI * 80 / 180, M_PI};
-    bool e1 = false, e2 = false, e3 = false;
+    bool e1 = false, e2 = false, e3 = false, e4 = false;
     for (int i = 0; i < 12; i++) {
       e1 = e1 || (fabs(qf[7 + i]) > qsec[i % 3]);
       e2 = e2 || (fabs(vs[i]) > 50);
       e3 = e3 || (fabs(tau[i]) > 8);
+      // NOT in the reference: its three comparisons are blind to NaN (`NaN > 8` is false), so a non-finite command -- e.g. the
+      // forces of an MPC solve that never finished -- would be passed to the motors.  A fourth sticky code stops the robot.
+      e4 = e4 || !(fabs(tau[i]) <= 1.7976931348623157e308) || !(fabs(qd[7 + i]) <= 1.7976931348623157e308) ||
+           !(fabs(vd[6 + i]) <= 1.7976931348623157e308);
     }
+    if (e4) err = 4;
     if (e1) err = 1;
     if (e2) err = 2;
     if (e3) err = 3;

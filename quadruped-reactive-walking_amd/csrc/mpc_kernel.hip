@@ -410,12 +410,13 @@ __device__ __forceinline__ unsigned q_load(const unsigned* p) { return __hip_ato
 // 2 s without a single finished task means the queue is really stuck.  The counter is read only when the 2 s have passed.
 struct SeqGiveUp {
   unsigned long long t0;
-  unsigned last;
+  unsigned last, limit;
   const unsigned* prog;
-  __device__ __forceinline__ SeqGiveUp(const unsigned* p) : t0(__builtin_amdgcn_s_memrealtime()), last(q_load(p)), prog(p) {}
+  __device__ __forceinline__ SeqGiveUp(const unsigned* p, unsigned ticks = 0u)
+      : t0(__builtin_amdgcn_s_memrealtime()), last(q_load(p)), limit(ticks ? ticks : 200000000u), prog(p) {}
   __device__ __forceinline__ bool expired() {
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    if (now - t0 <= 200000000ull) return false;
+    if (now - t0 <= (unsigned long long)limit) return false;
     const unsigned p = q_load(prog);
     if (p != last) { last = p; t0 = now; return false; }
     return true;
@@ -526,13 +527,19 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // have finished, which the takers see (`finished` == B) and leave.
 //   pre_ctr words: qrw_kernels.h (kPre*Word)
 constexpr int kPreHead = kPreTicketWord, kPreTail = kPreParksWord, kPreDone = kPreDoneWord, kPreErr = kPreErrWord, kPreProgress = kPreProgressWord;
+// error word of the time-sliced launch (1, 3, 4: a taker gave up waiting; 2: a level's queue overran) -- in pre_ctr for the
+// other workgroups of the launch and the host's getters, and in a host-mapped word that qrw_mpc_solve reads on entry
+__device__ __forceinline__ void pre_set_error(const MpcArgs& a, unsigned code) {
+  __hip_atomic_store(&a.pre_ctr[kPreErr], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.pre_err_host) __hip_atomic_store(a.pre_err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int NW>
 __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
   int task = -1;
   if (tid == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket < (unsigned)a.pre_cap) {
-      SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
+      SeqGiveUp clock(&a.pre_ctr[kPreProgress], a.giveup_ticks);
       bool gated = false;
       for (;;) {
         if (q_load(&a.pre_ctr[kPreTail]) > ticket) { gated = true; break; }
@@ -540,7 +547,7 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
         if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;               // somebody gave up already: do not wait another 2 s each
         __builtin_amdgcn_s_sleep(32);
         if (clock.expired()) {  // 2 s without any chunk of the launch ending: give up, loudly
-          __hip_atomic_store(&a.pre_ctr[kPreErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pre_set_error(a, 1u);
           break;
         }
       }
@@ -562,7 +569,7 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
             __builtin_amdgcn_s_sleep(8);
             if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;
             if (clock.expired()) {
-              __hip_atomic_store(&a.pre_ctr[kPreErr], 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              pre_set_error(a, 3u);
               break;
             }
           }
@@ -572,7 +579,7 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
           if (task >= 0) break;
           __builtin_amdgcn_s_sleep(2);
           if (clock.expired()) {
-            __hip_atomic_store(&a.pre_ctr[kPreErr], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre_set_error(a, 4u);
             break;
           }
         }
@@ -616,7 +623,7 @@ __device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool park
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreLevelWord + 2 * level + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (slot < (unsigned)a.pre_cap) __hip_atomic_store(&a.pre_queue[(size_t)level * a.pre_cap + slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_store(&a.pre_ctr[kPreErr], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else pre_set_error(a, 2u);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the level's tail is out before the gate opens for one more taker
       __hip_atomic_fetch_add(&a.pre_ctr[kPreTail], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -678,9 +685,14 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   // PRE: iteration this instance was parked at by an earlier chunk of THIS launch (0: a fresh solve; a workgroup that takes
   // its instance by index starts the solve whatever an aborted launch may have left behind)
   int it_resume = 0;
+  bool aborted = false;  // PRE: an earlier LAUNCH whose queue gave up left this instance parked: its state slots hold ADMM loop
+                         // variables, not OSQP's iterates -- this solve starts cold (zero x, z, y, rho 0.1: what OSQP's
+                         // store_solution leaves after a failed solve), its B coefficients / S flags are kept
   if constexpr (PRE) {
     // (agent-scope atomic loads: what another workgroup of THIS launch stored must never be served from a scalar or stale cache)
-    if ((int)blockIdx.x >= a.B) it_resume = __hip_atomic_load(&a.pause_it[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int pit = __hip_atomic_load(&a.pause_it[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)blockIdx.x >= a.B) it_resume = pit;
+    else aborted = (pit != 0);
   }
   const bool resumed = PRE && it_resume > 0;
   if constexpr (PRE) { if (tid < 8) L.sPre[tid] = 0.0; }
@@ -800,6 +812,15 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 5; c++) { zC[c] = ST(kStZC + c); yC[c] = ST(kStYC + c); }
+    if constexpr (PRE) {
+      if (aborted) {
+        rho = 0.1;
+#pragma unroll
+        for (int t = 0; t < 3; t++) xX[t] = xF[t] = zD[t] = yD[t] = yS[t] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) zC[c] = yC[c] = 0.0;
+      }
+    }
   }
 
   // B block: dt * I_inv * skew(lever) (MPC.cpp:213-232 first call, :425-447 afterwards)

@@ -58,6 +58,9 @@ struct qrw_handle_s {
   unsigned* pre_ctr = nullptr;
   int* pause_it = nullptr;
   int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0, pre_levels = 1, pre_bin = 200;
+  unsigned* pre_err_host = nullptr;  // pinned, host-mapped: the kernel's give-up code of a time-sliced launch (read on entry of the next)
+  unsigned* pre_err_dev = nullptr;   // its device address
+  unsigned giveup_ticks = 0;         // give-up clock in 100 MHz ticks (0: the kernel's default, 2 s)
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -319,6 +322,15 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
       if (const char* be = getenv("QRW_PREEMPT_BIN")) h->pre_bin = atoi(be);
       if (h->pre_bin < 25) h->pre_bin = 25;
       ALLOC(h->pre_queue, (size_t)h->pre_levels * B * (size_t)(h->pre_cmax > 1 ? h->pre_cmax - 1 : 1) * sizeof(int));
+      // the launch's error word, mirrored where the host can read it without synchronising the device
+      if (hipHostMalloc((void**)&h->pre_err_host, 64, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer((void**)&h->pre_err_dev, h->pre_err_host, 0) != hipSuccess) {
+        qrw_destroy(h);
+        return fail(-10, "qrw_create: hipHostMalloc of the time-sliced launch's error word");
+      }
+      h->pre_err_host[0] = 0u;
+      // tests: a short give-up clock (microseconds without any slice of the launch ending) forces the give-up path
+      if (const char* ge = getenv("QRW_PREEMPT_GIVEUP_US")) { const long us = atol(ge); if (us > 0 && us < 40000000) h->giveup_ticks = (unsigned)(us * 100); }
     }
   }
   {  // known answer through the instantiation of mpc_solve_kernel this handle's qrw_mpc_solve will launch
@@ -354,6 +366,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->plan_st); hipFree(h->ctrl_st);
   hipFree(h->seq_queue); hipFree(h->seq_ctr); hipFree(h->seq_hot); hipFree(h->seq_first);
   hipFree(h->pre_queue); hipFree(h->pre_ctr); hipFree(h->pause_it);
+  if (h->pre_err_host) hipHostFree(h->pre_err_host);
   hipFree(h->stage); hipFree(h->stage_i);
   delete h;
   return 0;
@@ -369,6 +382,19 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
                              int32_t num_iter_scalar, double* d_out, void* stream) {
   if (!h || !d_xref || !d_fsteps || !d_out) return fail(-1, "qrw_mpc_solve: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  if (h->pre_err_host) {
+    // A time-sliced launch whose queue gave up (never expected) wrote its code into a host-mapped word: seen here, at the next
+    // call that follows the failed launch's end, without a device sync.  Reported ONCE (this call launches nothing); the
+    // unfinished instances' results of that launch are NaN, and the next solve starts them cold (mpc_kernel.hip, `aborted`).
+    const unsigned code = __atomic_exchange_n(h->pre_err_host, 0u, __ATOMIC_ACQ_REL);
+    if (code != 0u) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "qrw_mpc_solve: an earlier time-sliced MPC launch of this handle gave up (code %u: %s); its unfinished "
+               "instances hold NaN results and restart cold at the next call", code,
+               code == 2u ? "a priority level's queue overran" : "a workgroup waited for a parked solve without any slice ending");
+      return fail(-12, msg);
+    }
+  }
   qrw::MpcArgs a;
   memset(&a, 0, sizeof(a));
   a.B = h->cfg.batch; a.N = h->cfg.n_steps; a.N_gait = h->cfg.N_gait; a.dt = h->cfg.dt_mpc;
@@ -383,6 +409,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
     a.pre_chunk = h->pre_chunk; a.pre_cmax = h->pre_cmax; a.pre_cap = h->cfg.batch * (h->pre_cmax - 1);
     a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
     a.pre_levels = h->pre_levels; a.pre_bin = h->pre_bin;
+    a.pre_err_host = h->pre_err_dev; a.giveup_ticks = h->giveup_ticks;
     HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_levels * a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
     HIP_OK(hipMemsetAsync(h->pre_ctr, 0, qrw::kPreCtrWords * sizeof(unsigned), (hipStream_t)stream), "qrw_mpc_solve: counter reset");
     // a solve that a given-up queue left unfinished (never expected; qrw_mpc_get_stats reports it) must not leave the previous
@@ -561,6 +588,26 @@ extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* c
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = c[qrw::kPreLevelWord + 2 * l + 1];
   *h_takers = c[qrw::kPreTicketWord];
   *h_finished = c[qrw::kPreDoneWord];
+  return 0;
+}
+
+extern "C" int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at) {
+  if (!h || parked_at < 1) return fail(-1, "qrw_test_poke_aborted: bad argument");
+  if (!h->pause_it || !mpc_time_sliced(h)) return fail(-1, "qrw_test_poke_aborted: not a time-sliced handle");
+  DeviceScope dev_scope__(h->cfg.device);
+  HIP_OK(hipDeviceSynchronize(), "qrw_test_poke_aborted sync");
+  const size_t B = h->cfg.batch, T = qrw::mpc_threads(h->cfg.n_steps);
+  std::vector<int> pit(B, parked_at);
+  HIP_OK(hipMemcpy(h->pause_it, pit.data(), B * sizeof(int), hipMemcpyHostToDevice), "qrw_test_poke_aborted pause_it");
+  // the iterate slots (items kStXX .. kStYC + 4) and rho: anything but what the last finished solve left
+  std::vector<double> st((size_t)qrw::kMpcStItems * T);
+  for (size_t b = 0; b < B; b++) {
+    double* d = h->mpc_st + b * qrw::kMpcStItems * T;
+    HIP_OK(hipMemcpy(st.data(), d, st.size() * sizeof(double), hipMemcpyDeviceToHost), "qrw_test_poke_aborted D2H");
+    for (size_t e = 0; e < (size_t)qrw::kStB * T; e++) st[e] = 3.7 * st[e] + 1.0 + 0.01 * (double)(e % 17);
+    for (size_t e = 0; e < T; e++) st[(size_t)qrw::kStRho * T + e] = 0.37;
+    HIP_OK(hipMemcpy(d, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice), "qrw_test_poke_aborted H2D");
+  }
   return 0;
 }
 

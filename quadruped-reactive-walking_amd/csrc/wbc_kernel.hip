@@ -968,20 +968,24 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       const double qd[3] = {qd_leg[0], qd_leg[1], qd_leg[2]};
       const double vd[3] = {vd_leg[0], vd_leg[1], vd_leg[2]};
       const double qsec[3] = {M_PI * 0.4, M_PI * 80 / 180, M_PI};
-      double e1 = 0.0, e2 = 0.0, e3 = 0.0;
+      double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         if (fabs(c_qf[t]) > qsec[t]) e1 = 1.0;
         if (fabs(c_vs[t]) > 50) e2 = 1.0;
         if (fabs(tff[t]) > 8) e3 = 1.0;
+        // not in the reference (its comparisons are blind to NaN): a non-finite command stops the robot, code 4 (glue::result)
+        if (!(fabs(tff[t]) <= 1.7976931348623157e308) || !(fabs(qd[t]) <= 1.7976931348623157e308) ||
+            !(fabs(vd[t]) <= 1.7976931348623157e308)) e4 = 1.0;
       }
-      e1 = quad_max(e1); e2 = quad_max(e2); e3 = quad_max(e3);
+      e1 = quad_max(e1); e2 = quad_max(e2); e3 = quad_max(e3); e4 = quad_max(e4);
       if (err == 0) {  // the WBC counts this iteration: keep its references for the next one
 #pragma unroll
         for (int t = 0; t < 3; t++) {
           cs[(size_t)(glue::cQDES + 3 * j + t) * cB] = qd[t];
           cs[(size_t)(glue::cVDES + 3 * j + t) * cB] = vd[t];
         }
+        if (e4 != 0.0) err = 4;
         if (e1 != 0.0) err = 1;
         if (e2 != 0.0) err = 2;
         if (e3 != 0.0) err = 3;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_mpc_get_order": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "qrw_test_poke_aborted": (C.c_int, [_vp, C.c_int32]),
     "qrw_mpc_get_slice_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
     "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),

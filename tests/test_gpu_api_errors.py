@@ -134,3 +134,73 @@ def test_tensor_on_wrong_device_or_dtype_is_refused():
         eng.copy_mpc_iters(torch.zeros((2,), dtype=torch.int64, device="cuda"))
     # the handle's device survives a change of torch's current device only through the explicit device check
     assert eng.device == 0 and torch.cuda.current_device() == 0
+
+
+def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(synth_mod, oracle_mod, monkeypatch):
+    """A time-sliced MPC launch (N > 16) whose queue gives up -- forced here with a 20 us give-up clock: the queue-fed workgroups
+    leave before the first slice of 600 iterations (~2 ms) can end, so nobody finishes the parked solves -- must be visible where
+    the loop runs: (1) the unfinished results are NaN, (2) the controller's fourth error code stops those robots on the same
+    iteration (the reference's three `> limit` tests are blind to NaN, scripts/Controller.py:341-365), (3) the NEXT
+    qrw_mpc_solve returns -12, once, without a device sync in between, (4) the call after it runs and starts the unfinished
+    instances cold: same iteration count and result as an oracle that is re-created at that call's inputs."""
+    import torch
+    import qrw_hip
+    from Controller import Controller_batch
+
+    monkeypatch.setenv("QRW_PREEMPT_MIN_BATCH", "0")
+    monkeypatch.setenv("QRW_PREEMPT_GIVEUP_US", "20")
+    B, N, Ng = 6, 32, 36
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=Ng, gaits=("trot",), seed0=424200)
+    eng = qrw_hip.Batch(B, N, N_gait=Ng, T_gait=0.02 * N)
+    d0, d1, d2 = sb.step(0), sb.step(1), sb.step(2)
+    x = lambda d: torch.from_numpy(d["xref"]).cuda()
+    f = lambda d: torch.from_numpy(d["fsteps"]).cuda()
+    out0 = eng.mpc_solve(x(d0), f(d0), 0).clone()          # gives up: every solve needs more than one slice
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out0).any(dim=(1, 2)).all()), "every first solve of this workload takes more than 600 iterations"
+    with pytest.raises(qrw_hip.QrwError) as ei:
+        eng.mpc_solve(x(d1), f(d1), 1)                     # (3): reported here, nothing launched
+    assert "(-12)" in str(ei.value)
+    with pytest.raises(qrw_hip.QrwError):
+        eng.mpc_stats()                                    # the getter still says so too (it reads the launch's own counters)
+    monkeypatch.delenv("QRW_PREEMPT_GIVEUP_US")            # (the clock is read at creation: this handle keeps its 20 us)
+    # (4) the next call runs; with the same short clock it gives up again, so take a handle with the default clock and poke the
+    # aborted state into it: pause_it != 0 and the slots holding loop variables -- what the failed launch left behind
+    eng2 = qrw_hip.Batch(B, N, N_gait=Ng, T_gait=0.02 * N)
+    eng2.mpc_solve(x(d0), f(d0), 0)
+    torch.cuda.synchronize()
+    assert qrw_hip.load_library().qrw_test_poke_aborted(eng2._handle, 600) == 0
+    out = eng2.mpc_solve(x(d1), f(d1), 1)
+    torch.cuda.synchronize()
+    it = eng2.mpc_stats()["iters"]
+    for b in (0, B - 1):
+        m = oracle_mod.MPC(0.02, N, 0.02 * N, Ng)
+        m.run(0, d0["xref"][b], d0["fsteps"][b])           # sets B / S up as the first call did
+        m.cold_start()                                     # OSQP: x, z, y = 0, rho = 0.1 (store_solution after a failed solve)
+        m.run(1, d1["xref"][b], d1["fsteps"][b])
+        assert m.iter == it[b]
+        np.testing.assert_allclose(out[b].cpu().numpy(), m.get_latest_result(), rtol=1e-6, atol=1e-8)
+
+    # (2) through the control loop: NaN forces -> code 4 -> security output on the same iteration
+    monkeypatch.setenv("QRW_PREEMPT_GIVEUP_US", "20")
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", "200")         # (a solve from standstill may end within 600 iterations: cut at 200)
+    q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
+    ctl = Controller_batch(B, q_init, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=Ng)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    vref = t(np.tile(np.array([0.3, 0.0, 0, 0, 0, 0.1]), (B, 1)))
+    qf = np.zeros((B, 19))
+    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, q_init
+    qf, vf, rpy, vs = t(qf), t(np.zeros((B, 18))), t(np.zeros((B, 3))), t(np.zeros((B, 12)))
+    raised_at = None
+    for k in range(21):
+        try:
+            r = ctl.compute(vref, qf, vf, rpy, vs)
+        except qrw_hip.QrwError as e:
+            raised_at = k
+            assert "(-12)" in str(e)
+            break
+        torch.cuda.synchronize()
+        if k >= 1:  # (iteration 0 still uses the default result, scripts/MPC_Wrapper.py:123-126)
+            assert bool((ctl.error_flag == 4).all()), (k, ctl.error_flag)
+            assert float(r.tau_ff.abs().max()) == 0.0 and float(r.P.abs().max()) == 0.0 and bool((r.D == 0.1).all())
+    assert raised_at == 10  # the next MPC call of the loop
