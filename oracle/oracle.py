@@ -104,6 +104,7 @@ def load(fast=False):
         "planner_oracle_get_xref": (None, [vp, _dp]),
         "planner_oracle_get_footsteps": (None, [vp, _dp, _dp, _dp]),
         "planner_oracle_get_feet": (None, [vp, _dp, _dp, _dp, _dp, _dp]),
+        "planner_oracle_get_Rz": (None, [vp, _dp]),
         "mpc_oracle_run_batch": (C.c_int, [C.POINTER(vp), C.c_int, _ip, _dp, _dp, _dp, C.c_int]),
         "wbc_oracle_compute_batch": (C.c_int, [C.POINTER(vp), C.c_int] + [_dp] * 11 + [C.c_int]),
     }
@@ -556,6 +557,12 @@ class Planner:
         x = np.zeros((12, self.n_steps + 1))
         self._lib.planner_oracle_get_xref(self._h, _ptr(x))
         return x
+
+    def Rz(self):
+        """FootstepPlanner::getRz (src/FootstepPlanner.cpp:236)."""
+        r = np.zeros((3, 3))
+        self._lib.planner_oracle_get_Rz(self._h, _ptr(r))
+        return r
 
     def footsteps(self):
         f, t, ot = np.zeros((self.N_gait, 12)), np.zeros((3, 4)), np.zeros((3, 4))

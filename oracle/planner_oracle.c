@@ -29,6 +29,8 @@ struct planner_oracle {
   /* FootstepPlanner */
   double dt_wbc, k_feedback, g, L;
   double shoulders[12], currentFootstep[12], targetFootstep[12], o_targetFootstep[12], nextFootstep[12]; /* 3x4 row-major */
+  double Rz[9]; /* FootstepPlanner::Rz (3x3 row-major): zero but (2,2) = 1 after initialize (FootstepPlanner.cpp:10,48), then whatever
+                 * the member was last assigned -- after updateFootsteps always computeTargetFootstep's rotation by the base yaw (:214) */
   double *footsteps; /* N_gait x 3 x 4 */
   double *dt_cum, *yaws, *dx, *dy;
   /* FootTrajectoryGenerator */
@@ -281,6 +283,9 @@ void planner_oracle_footsteps_update(planner_oracle *o, int refresh, int k, cons
   double rpy[3];
   quat_to_rpy(q7 + 3, rpy);
   c = cos(rpy[2]); s = sin(rpy[2]);
+  /* Rz.topLeftCorner<2, 2>() << c, -s, s, c  (FootstepPlanner.cpp:214): the member's last assignment of an updateFootsteps call
+   * (the earlier ones, :63 and :149, are overwritten before the call returns) */
+  o->Rz[0] = c; o->Rz[1] = -s; o->Rz[3] = s; o->Rz[4] = c;
   for (int i = 0; i < 4; i++) {
     double x = o->targetFootstep[0 * 4 + i], y = o->targetFootstep[1 * 4 + i];
     o->o_targetFootstep[0 * 4 + i] = (c * x - s * y) + q7[0];
@@ -400,6 +405,7 @@ planner_oracle *planner_oracle_create(double dt_mpc, double dt_wbc, double T_gai
   memcpy(o->currentFootstep, shoulders3x4, 12 * sizeof(double));
   memcpy(o->targetFootstep, shoulders3x4, 12 * sizeof(double));
   memcpy(o->o_targetFootstep, shoulders3x4, 12 * sizeof(double));
+  memset(o->Rz, 0, sizeof(o->Rz)); o->Rz[8] = 1.0; /* FootstepPlanner.cpp:10,48 */
   o->footsteps = (double *)calloc(N_gait * 12, sizeof(double));
   o->dt_cum = (double *)calloc(N_gait, sizeof(double)); o->yaws = (double *)calloc(N_gait, sizeof(double));
   o->dx = (double *)calloc(N_gait, sizeof(double)); o->dy = (double *)calloc(N_gait, sizeof(double));
@@ -442,6 +448,7 @@ void planner_oracle_get_footsteps(const planner_oracle *o, double *fsteps_Ngx12,
   if (target3x4) memcpy(target3x4, o->targetFootstep, sizeof(o->targetFootstep));
   if (o_target3x4) memcpy(o_target3x4, o->o_targetFootstep, sizeof(o->o_targetFootstep));
 }
+void planner_oracle_get_Rz(const planner_oracle *o, double *out9) { memcpy(out9, o->Rz, sizeof(o->Rz)); } /* FootstepPlanner::getRz :236 */
 void planner_oracle_get_feet(const planner_oracle *o, double *pos, double *vel, double *acc, double *t0s, double *t_swing) {
   if (pos) memcpy(pos, o->position, sizeof(o->position));
   if (vel) memcpy(vel, o->velocity, sizeof(o->velocity));

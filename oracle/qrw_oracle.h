@@ -122,6 +122,7 @@ void planner_oracle_get_gaits(const planner_oracle *o, double *past, double *cur
 void planner_oracle_get_flags(const planner_oracle *o, double *out4); /* newPhase, is_static, remainingTime, #swing feet */
 void planner_oracle_get_xref(const planner_oracle *o, double *xref);
 void planner_oracle_get_footsteps(const planner_oracle *o, double *fsteps_Ngx12, double *target3x4, double *o_target3x4);
+void planner_oracle_get_Rz(const planner_oracle *o, double *out3x3); /* FootstepPlanner::getRz, FootstepPlanner.cpp:236 */
 void planner_oracle_get_feet(const planner_oracle *o, double *pos, double *vel, double *acc, double *t0s, double *t_swing);
 
 /* batched helpers for the bench's cpu_baseline leg: `threads` OpenMP threads over instances */

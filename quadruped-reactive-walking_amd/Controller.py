@@ -56,7 +56,7 @@ class Controller_batch:
                                 T_gait=float(T_gait), dt_wbc=float(dt_wbc), device=device)
         qi = np.broadcast_to(np.asarray(q_init, dtype=np.float64).reshape(-1, 12), (self.B, 12))
         self._b.planner_init(k_mpc=self.k_mpc, h_ref=self.h_ref)
-        self._b.controller_init(torch.from_numpy(np.ascontiguousarray(qi)).to(self.dev), self.h_ref)
+        self._b.controller_init(torch.from_numpy(np.array(qi, dtype=np.float64, order="C")).to(self.dev), self.h_ref)
         # Default MPC result before the first solve is collected (scripts/MPC_Wrapper.py:64-71,123-126)
         first = np.zeros((self.B, 24, self.n_steps))
         first[:, 2, 0] = self.h_ref

@@ -41,7 +41,7 @@ struct PS {  // accessor of one instance's planner state (item-major)
 
 struct Lay {  // item offsets for a given N_gait
   int past, cur, des, cf, fs, tgt, otgt, t0s, tsw, ax, ay, pos, vel, acc, fttgt, feet, nfeet, newphase, isstatic, remain,
-      qstatic, total;
+      qstatic, rz, total;
 };
 __host__ __device__ inline Lay make_layout(int Ng) {
   Lay L;
@@ -69,6 +69,7 @@ __host__ __device__ inline Lay make_layout(int Ng) {
   L.isstatic = o; o += 1;
   L.remain = o; o += 1;
   L.qstatic = o; o += 7;
+  L.rz = o; o += 2;  // cos / sin of FootstepPlanner::Rz as its last updateFootsteps left it (getRz, FootstepPlanner.cpp:214,236)
   L.total = o;
   return L;
 }
@@ -370,6 +371,7 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b, long l
     for (int e = 0; e < 4; e++) { s(L.t0s + e) = 0.0; s(L.tsw + e) = 0.0; s(L.feet + e) = 0.0; }
     for (int e = 0; e < 7; e++) s(L.qstatic + e) = 0.0;
     s(L.newphase) = 0.0; s(L.isstatic) = 0.0; s(L.remain) = 0.0; s(L.nfeet) = 0.0;
+    s(L.rz) = 0.0; s(L.rz + 1) = 0.0;  // Rz = 0 but (2,2) = 1 until the first updateFootsteps (FootstepPlanner.cpp:10,48)
   } else if (uses_gait) {
     gm_load(s, L.past, past);
     gm_load(s, L.cur, cur);
@@ -539,6 +541,7 @@ __device__ __forceinline__ void planner_body(const PlannerArgs& a, int b, long l
     }
     PP(5);
     const double c = cos(rpy[2]), sn = sin(rpy[2]);
+    s(L.rz) = c; s(L.rz + 1) = sn;
 #pragma unroll
     for (int f = 0; f < 4; f++) {
       s(L.tgt + f) = tg[0][f];
@@ -967,6 +970,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   double otgt[3];
   {
     const double c = cos(rpy[2]), sn = sin(rpy[2]);
+    if (j == 0) { s(L.rz) = c; s(L.rz + 1) = sn; }
     s(L.tgt + j) = tg[0];
     s(L.tgt + 4 + j) = tg[1];
     s(L.tgt + 8 + j) = 0.0;
@@ -1184,6 +1188,7 @@ int planner_item_offset(int N_gait, int which) {
     case 15: return L.cf;
     case 16: return L.qstatic;
     case 17: return L.fttgt;
+    case 18: return L.rz;
     default: return -1;
   }
 }

@@ -171,6 +171,13 @@ class Gait:
         self._core.batch.planner_call_host(qrw_hip.PLAN_GAIT, k=int(k), q7=np.asarray(q, dtype=np.float64).ravel()[:7][None],
                                            code=int(joystickCode), want=())
 
+    def setGait(self, gaitMatrix):
+        """Gait::setGait (src/Gait.cpp:262-269, python/gepadd.cpp:98): the reference prints the matrix it receives and returns
+        false without touching the gait -- its body ends in a "Todo"."""
+        print("Gait matrix received by setGait:")
+        print(np.asarray(gaitMatrix))
+        return False
+
     def changeGait(self, code, q):
         # Gait::changeGait alone (src/Gait.cpp:194-219): an updateGait with k not a multiple of k_mpc never rolls
         self._core.batch.planner_call_host(qrw_hip.PLAN_GAIT, k=1 if self._core.cfg["k_mpc"] > 1 else 0,
@@ -231,6 +238,13 @@ class FootstepPlanner:
 
     def getTargetFootsteps(self):
         return self._core.batch.planner_get(7, 12).reshape(3, 4)
+
+    def getRz(self):
+        """FootstepPlanner::getRz (src/FootstepPlanner.cpp:236, python/gepadd.cpp:123): the member as the last updateFootsteps left
+        it -- the rotation by the base yaw that takes the target footsteps to the world frame (:214); zero but (2,2) = 1 before
+        the first call (:10,:48).  The kernel keeps the yaw's cosine and sine in the planner state."""
+        c, s = self._core.batch.planner_get(18, 2)
+        return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
 
 
 class FootTrajectoryGenerator:

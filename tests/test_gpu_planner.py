@@ -90,9 +90,16 @@ def test_planner_dropin_classes_match_oracle(oracle_mod):
     q = np.zeros((19, 1))
     q[2, 0], q[6, 0] = h_ref, 1.0
     vref = np.array([0.5, 0.1, 0, 0, 0, 0.3])
+    # FootstepPlanner::getRz (python/gepadd.cpp:123): zero but (2,2) = 1 before the first update (src/FootstepPlanner.cpp:10,48)
+    assert np.array_equal(footstepPlanner.getRz(), np.diag([0.0, 0.0, 1.0])) and np.array_equal(ref.Rz(), np.diag([0.0, 0.0, 1.0]))
+    assert gait.setGait(np.ones((N_gait, 4))) is False  # Gait::setGait prints and returns false (src/Gait.cpp:262-269)
     for k in range(0, 45):
         h_v = (vref + rng.uniform(-0.05, 0.05, 6)).reshape(6, 1)
         code = 2 if k == 23 else 0
+        # a base that yaws (and rolls / pitches a little): quaternion x, y, z, w of rpy = (0.02, -0.03, 0.015 k)
+        cr, sr, cp, sp, cy, sy = np.cos(0.01), np.sin(0.01), np.cos(-0.015), np.sin(-0.015), np.cos(0.0075 * k), np.sin(0.0075 * k)
+        q[3:7, 0] = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+        q[0, 0], q[1, 0] = 0.01 * k, -0.004 * k
         gait.updateGait(k, k_mpc, q[0:7, 0:1], code)
         o_target = footstepPlanner.updateFootsteps(k % k_mpc == 0 and k != 0, int(k_mpc - k % k_mpc), q[0:7, 0:1],
                                                    h_v.copy(), vref)
@@ -105,6 +112,8 @@ def test_planner_dropin_classes_match_oracle(oracle_mod):
         assert np.allclose(statePlanner.getReferenceStates(), ref.xref(), rtol=1e-12, atol=1e-13)
         assert np.allclose(footstepPlanner.getFootsteps(), f, rtol=1e-11, atol=1e-13) and np.allclose(o_target, otg, atol=1e-13)
         assert np.array_equal(gait.getCurrentGait(), ref.gaits()[1]) and gait.getIsStatic() == ref.flags()["is_static"]
+        Rz = footstepPlanner.getRz()
+        assert Rz.shape == (3, 3) and np.allclose(Rz, ref.Rz(), rtol=0, atol=1e-14) and abs(Rz[1, 0] - np.sin(0.015 * k)) < 1e-12
         assert np.allclose(ftg.getFootPosition(), pos, atol=1e-11) and np.allclose(ftg.getFootVelocity(), vel, atol=1e-10)
         assert np.allclose(ftg.getFootAcceleration(), acc, atol=1e-8)
 
