@@ -351,6 +351,8 @@ def main():
             if B % 2 == 0:  # the same loop with the fleet as two stream groups (Controller_batch(groups=2), opt-in)
                 out["secondary_ratio_1_10_two_groups"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2)
                 out["secondary_ratio_1_10_two_groups_free"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2, free_running=True)
+                out["secondary_ratio_1_10_two_groups_staggered"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2, free_running=True,
+                                                                                        stagger=True)
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
         if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
             # the metric reads "batch {1, 256, 4096}" and BASELINE lists configs 2 and 4: every single-GPU figure in this ONE line
@@ -722,7 +724,8 @@ def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
                     "%d timed calls after %d warm-up calls, inputs replayed from HBM" % (K, W)}
 
 
-def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=32, groups=1, free_running=False):
+def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=32, groups=1, free_running=False,
+                         stagger=False):
     """Secondary figure: the reference's own 1:10 MPC:WBC ratio, whole Controller.compute iterations
     (scripts/Controller.py:200-326) on the device — updateState, the four planners, one MPC solve every k_mpc
     iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM.
@@ -730,7 +733,8 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     compute-unit-masked streams.  Reports the free-running rate and the iteration latency when paced at dt_wbc = 2 ms.
     groups = 2: the fleet as two stream groups (Controller_groups), results identical; free_running = True additionally
     keeps the stand-in for the robots (perfect tracking of the PD targets) per group on the group's stream, so that the
-    groups are never joined and one group's straggling solves run beside the other group's iterations."""
+    groups are never joined and one group's straggling solves run beside the other group's iterations.
+    stagger = True: group g starts g * k_mpc / groups ticks late (Controller_groups), so the groups solve on different ticks."""
     import torch
 
     from Controller import Controller_batch
@@ -740,7 +744,7 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     with torch.cuda.stream(torch.cuda.Stream(dev)):
         ctl = Controller_batch(B, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=k_mpc, T_gait=0.02 * N, T_mpc=0.02 * N,
                                N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing, loop_cus=loop_cus,
-                               groups=groups)
+                               groups=groups, stagger=stagger)
         # half the joystick range of the headline workload: at up to 1.5 m/s a sixth of the instances run into the
         # controller's joint-limit / torque security stop within 100 iterations (reference behaviour), which would
         # make the figure depend on how many robots have already been stopped
@@ -759,8 +763,9 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
                     sl = ctl.slice_of(g)
                     with torch.cuda.stream(ctl.stream_of(g)):
                         r = ctl.compute_group(g, vref[sl], qf[sl], vf[sl], rpy[sl], vs[sl])
-                        qf[sl, 7:].copy_(r.q_des)
-                        vf[sl, 6:].copy_(r.v_des)
+                        if ctl.group_started(g):
+                            qf[sl, 7:].copy_(r.q_des)
+                            vf[sl, 6:].copy_(r.v_des)
                 return
             r = ctl.compute(vref, qf, vf, rpy, vs)
             qf[:, 7:].copy_(r.q_des)  # perfect tracking of the PD targets stands in for the robot
@@ -799,6 +804,8 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     if groups > 1:
         what += "; fleet as %d stream groups (%s)" % (groups, "never joined: the robots' stand-in runs per group" if free_running
                                                       else "joined on the caller's stream every iteration")
+        if stagger:
+            what += "; staggered: group g started g * k_mpc / groups ticks late, the groups' solves fall on different ticks"
     if multiprocessing:
         what += ("; asynchronous MPC mode: solves on their own stream (224 compute units), the control loop on a stream "
                  "with the other 32, a result adopted when its event has completed")

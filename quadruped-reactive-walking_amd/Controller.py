@@ -28,7 +28,7 @@ class Controller_batch:
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
-                 _out_views=None):
+                 stagger=False, _out_views=None):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
 
         groups: None / 1 = one handle; G > 1 = the fleet as G stream groups (Controller_groups).  Not the default: in the 1:10
@@ -36,6 +36,9 @@ class Controller_batch:
         for the single handle (twice the launches, one join per iteration), never joined (compute_group on the groups' own
         streams) at 10.95 M; the paced worst-case latency (5.6 ms, the iteration that carries the solve) is the same in all
         three -- only the asynchronous mode (0.35 ms) removes it (bench.py, secondary_ratio_1_10*).
+
+        stagger (groups > 1 only): group g starts g * k_mpc / groups fleet ticks late, so the groups' MPC solves fall on
+        different ticks and one group's solve runs beside the other's plain iterations (Controller_groups).
 
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
         on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
@@ -241,7 +244,7 @@ class Controller_groups(Controller_batch):
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
-                 _out_views=None):
+                 stagger=False, _out_views=None):
         import torch
 
         G = int(groups) if groups is not None else 2
@@ -253,7 +256,15 @@ class Controller_groups(Controller_batch):
         self.k, self.k_mpc, self.h_ref, self.dt_wbc = 0, int(k_mpc), float(h_ref), float(dt_wbc)
         self.n_steps = int(round(T_mpc / dt_mpc))
         self.multiprocessing, self.fused = bool(multiprocessing), bool(fused)
-        self._fleet_result = torch.empty((self.B, 5, 12), dtype=torch.float64, device=self.dev)
+        self._fleet_result = torch.zeros((self.B, 5, 12), dtype=torch.float64, device=self.dev)
+        # stagger: group g starts g * k_mpc / G fleet ticks late, so that the groups solve on different ticks (the reference solves
+        # on k % k_mpc == 0 of the robot's OWN clock, scripts/Controller.py:246-253: every robot of group g still sees exactly
+        # the single-handle controller, started that many ticks later).  On the device the late group's first iteration waits
+        # for group 0 to have reached the same tick, which is what takes the two groups' solves apart.
+        self.stagger = bool(stagger)
+        self._delay = [(g * int(k_mpc)) // G if self.stagger else 0 for g in range(G)]
+        self._calls = [0] * G
+        self._tick_ev = {}
         self.error_flag = torch.zeros((self.B,), dtype=torch.int32, device=self.dev)
         self.result = Result(self._fleet_result)
         qi = np.broadcast_to(np.asarray(q_init, dtype=np.float64).reshape(-1, 12), (self.B, 12))
@@ -273,25 +284,45 @@ class Controller_groups(Controller_batch):
     def slice_of(self, g):
         return self._sl[g]
 
+    def group_started(self, g):
+        """False while a staggered group has not run its first iteration yet (its slice of the result is still zero)."""
+        return self._calls[g] > self._delay[g]
+
     def stream_of(self, g):
         return self.streams[g]
 
     def compute_group(self, g, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
-        """One control iteration of group g alone: arguments are that group's slices (contiguous, leading dimension
-        batch / groups), enqueued on the CURRENT stream -- call it under `torch.cuda.stream(ctl.stream_of(g))`."""
-        code = joystick_code[self._sl[g]] if self._torch.is_tensor(joystick_code) else joystick_code
-        return self.groups[g].compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, code)
+        """One control iteration (fleet tick) of group g alone: EVERY argument is that group's slice (contiguous, leading
+        dimension batch / groups; a tensor joystick_code too), enqueued on the CURRENT stream -- call it under
+        `torch.cuda.stream(ctl.stream_of(g))`, once per fleet tick and group.  With stagger=True the first
+        g * k_mpc / groups calls of group g do nothing (its robots have not started yet: its slice of the result stays zero,
+        its error flags 0) and return that slice."""
+        torch = self._torch
+        t = self._calls[g]
+        self._calls[g] = t + 1
+        if g == 0:
+            self.k = t + 1
+        if t < self._delay[g]:
+            return Result(self._fleet_result[self._sl[g]])
+        if self.stagger and g > 0 and t == self._delay[g] and t in self._tick_ev:
+            torch.cuda.current_stream(self.dev).wait_event(self._tick_ev[t])  # group 0 has finished its first t ticks
+        r = self.groups[g].compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+        if self.stagger and g == 0 and (t + 1) in self._delay[1:]:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._tick_ev[t + 1] = ev
+        return r
 
     def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
         for g, (sl, st) in enumerate(zip(self._sl, self.streams)):
             st.wait_stream(caller)  # the inputs produced on the caller's stream are ready
+            code = joystick_code[sl] if torch.is_tensor(joystick_code) else joystick_code
             with torch.cuda.stream(st):
-                self.compute_group(g, joy_v_ref[sl], q_filt[sl], v_filt[sl], rpy[sl], v_secu[sl], joystick_code)
+                self.compute_group(g, joy_v_ref[sl], q_filt[sl], v_filt[sl], rpy[sl], v_secu[sl], code)
         for st in self.streams:
             caller.wait_stream(st)
-        self.k += 1
         return self.result
 
     def stop_parallel_loop(self):

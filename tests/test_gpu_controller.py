@@ -349,3 +349,71 @@ def test_stream_groups_controller_equals_the_single_handle(mode):
     assert torch.equal(got, ref) and torch.equal(flag, ref_flag)
     with pytest.raises(Exception):
         Controller_batch(7, Q_INIT, groups=2)
+
+
+@pytest.mark.parametrize("free", [False, True])
+def test_staggered_stream_groups_equal_single_handles_started_late(free):
+    """Controller_batch(..., groups=2, stagger=True): group 1 starts k_mpc / 2 fleet ticks late, so the two groups' MPC solves fall
+    on different ticks (the reference solves on k % k_mpc == 0 of the robot's own clock, scripts/Controller.py:246-253).  Every
+    robot must see exactly a single-handle controller started that many ticks later: Result and error flag of group g at fleet
+    tick t equal, bit for bit, those of a single handle over the group's robots at its tick t - delay; before its start a
+    group's slice of the result is zero.  Joined (compute) and never joined (compute_group on the groups' streams)."""
+    import torch
+    from Controller import Controller_batch, Controller_groups
+
+    B, iters, k_mpc = 32, 27, 10
+    rng = np.random.default_rng(11)
+    qi = Q_INIT + rng.uniform(-0.03, 0.03, (B, 12))
+    vref = _t(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0]))
+    code = torch.zeros((B,), dtype=torch.int32, device="cuda")  # a per-robot joystick code tensor goes through both entry points
+
+    def state(n, q0):
+        qf = torch.zeros((n, 19), dtype=torch.float64, device="cuda")
+        qf[:, 2], qf[:, 6] = 0.2229, 1.0
+        qf[:, 7:] = _t(q0)
+        vf = torch.zeros((n, 18), dtype=torch.float64, device="cuda")
+        return qf, vf, torch.zeros((n, 3), dtype=torch.float64, device="cuda"), torch.zeros((n, 12), dtype=torch.float64, device="cuda")
+
+    ctl = Controller_batch(B, qi, groups=2, stagger=True, k_mpc=k_mpc)
+    assert isinstance(ctl, Controller_groups) and ctl._delay == [0, k_mpc // 2]
+    qf, vf, rpy, vs = state(B, qi)
+    vf[:, :6] = vref
+    hist = []
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for t in range(iters):
+            if free:
+                for g in range(2):
+                    sl = ctl.slice_of(g)
+                    with torch.cuda.stream(ctl.stream_of(g)):
+                        r = ctl.compute_group(g, vref[sl], qf[sl], vf[sl], rpy[sl], vs[sl], code[sl])
+                        if ctl.group_started(g):
+                            qf[sl, 7:].copy_(r.q_des)
+                            vf[sl, 6:].copy_(r.v_des)
+                for g in range(2):
+                    ctl.stream_of(g).synchronize()
+            else:
+                r = ctl.compute(vref, qf, vf, rpy, vs, code)
+                for g in range(2):
+                    if ctl.group_started(g):
+                        sl = ctl.slice_of(g)
+                        qf[sl, 7:].copy_(r.q_des[sl])
+                        vf[sl, 6:].copy_(r.v_des[sl])
+                torch.cuda.current_stream().synchronize()
+            hist.append(ctl._fleet_result.clone())
+        flags = ctl.error_flag.clone()
+    assert ctl.k == iters
+    for g in range(2):
+        sl, d = ctl.slice_of(g), ctl._delay[g]
+        one = Controller_batch(B // 2, qi[sl], k_mpc=k_mpc)
+        q1, v1, rpy1, vs1 = state(B // 2, qi[sl])
+        v1[:, :6] = vref[sl]
+        for t in range(iters):
+            if t < d:
+                assert float(hist[t][sl].abs().max()) == 0.0
+                continue
+            r = one.compute(vref[sl], q1, v1, rpy1, vs1, code[sl])
+            q1[:, 7:].copy_(r.q_des)
+            v1[:, 6:].copy_(r.v_des)
+            torch.cuda.synchronize()
+            assert torch.equal(hist[t][sl], one._res["result"]), (g, t)
+        assert torch.equal(flags[sl], one.error_flag)
