@@ -7,8 +7,32 @@
 
 namespace qrw {
 
-constexpr int kCol = 14;           // column stride of a chain matrix in LDS (bank-conflict-free in both orientations)
-constexpr int kSlot = 12 * kCol;  // chain-matrix slot (12x12, column-major)
+// LDS layout of the chain matrices.  Column stride 14 doubles: entry (i,c) at c*14+i -- the forward access (ds_read_b64, lane i
+// reads (i,c)) and the transposed one (ds_read_b128, lane i reads two entries of row i of M') are free of bank conflicts WITHIN
+// a chain.  ACROSS the two chains they are not: both chains are read by one instruction (chain A in DPP row 0, chain B in row 1,
+// i.e. lanes 0-15 / 16-31 of the same bank group: ds_read_b64 is served in two groups of 32 lanes, ds_read_b128 in four groups
+// of 16 -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 --, 64 banks of 4 bytes), and with the slot stride 168 every
+// sweep read is a 2-way conflict: SQ_LDS_BANK_CONFLICT is a third of the kernel's LDS-array cycles.
+// -DQRW_BANK_FREE_LAYOUT=1 (round 4, measured, NOT the default) removes them: chain B's slot must sit 32 banks from chain A's in
+// the forward sweep (slot distance m) and 0 banks in the backward sweep (slot distance m - 1), which a slot stride of 176
+// doubles (= 32 banks mod 64) and a gap of 16 doubles in front of chain B's slots give (even m; odd m: no gap); lanes 12-15 of
+// a row repeat an address of their own lane group.  Counters at batch 4096 (profiles/r4_pmc_lds_contention.txt):
+// SQ_LDS_BANK_CONFLICT 0.165 -> 0.029 of the wave cycles, SQ_LDS_IDX_ACTIVE 0.497 -> 0.362 -- and the launch time does not move
+// (677 k control steps/s either way): the LDS array is not what the four wavefronts of a compute unit compete for.  Not shipped:
+// it costs 1.1 KB of LDS per instance and the N = 32 instantiations a few dwords of scratch (their LDS struct exceeds 64 KB).
+#ifndef QRW_BANK_FREE_LAYOUT
+#define QRW_BANK_FREE_LAYOUT 0
+#endif
+constexpr int kCol = 14;                                  // column stride of a chain matrix in LDS
+constexpr int kSlot = QRW_BANK_FREE_LAYOUT ? 176 : 168;   // slot stride (12 * kCol = 168 used)
+__host__ __device__ constexpr int chain_gap(int m) { return (QRW_BANK_FREE_LAYOUT && !(m & 1)) ? 16 : 0; }  // doubles in front of chain B's slots
+__host__ __device__ constexpr int chain_slot(int slot, int m) { return slot * kSlot + (slot >= m ? chain_gap(m) : 0); }
+// row whose transposed entries a lane reads in the backward sweep (lanes 12-15 have none)
+__device__ __forceinline__ int chain_row_t(int lane) {
+  const int l = lane & 15;
+  return (l < 12) ? l : (QRW_BANK_FREE_LAYOUT ? l - 12 : 11);
+}
+__host__ __device__ constexpr int chain_lds_doubles(int slots, int m) { return slots * kSlot + chain_gap(m); }
 
 // ---------------------------------------------------------------------------------------------------------
 // 12x12 row-times-vector step on the FP64 VALU: returns r + sum_c m[c] * x(lane c of this 16-lane row).
@@ -48,6 +72,7 @@ __device__ __forceinline__ double dpp_step12(double r, double x, const double (&
 //   apart -- are free of bank conflicts, 56 clocks per 12x12 operand, scripts/ubench/lds_rate.hip):
 //     slot s < m : -N_{s+1},        N_k  = C_k Delta_{k-1}^-1        (k = 1..m)
 //     slot s >= m: -Nt_{N-2-(s-m)}, Nt_k = C_{k+1}' Delta_{k+1}^-1   (k = m..N-2; slot m + N-2-k)
+//     slot s at chain_slot(s, m) doubles from the base (see kSlot above)
 //   vectors: step k lives at position pos(k) = k (k <= m), m + N - k (k > m); position N holds zeros.
 // Forward:  A: u_k = r_k - N_k u_{k-1};  B: u_k = r_k - Nt_k u_{k+1};  root: u_m = r_m - N_m u_{m-1} - Nt_m u_{m+1}.
 // In place in sX (u overwrites r).  NC > 0: compile-time N (fully unrolled), NC == 0: runtime N.
@@ -89,7 +114,7 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
   const int h = lane >> 5;
   const bool rw = (lane & 16) != 0;
   const bool own = (lane & 15) < 12;
-  const double* pm = sN + (rw ? m * kSlot : 0) + h * kSlot + i;  // pair p: + 2p*kSlot + c*kCol
+  const double* pm = sN + (rw ? m * kSlot + chain_gap(m) : 0) + h * kSlot + i;  // pair p: + 2p*kSlot + c*kCol
   double* px = sX + (rw ? (m + 1) * 12 : 0) + i;                 // step t: + t*12
   const double* pr = px + h * 12;                                // rhs of pair p: + (2p+1)*12
   double* dump = sDump + i;
@@ -149,7 +174,8 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   const int h = lane >> 5;
   const bool rw = (lane & 16) != 0;
   const bool own = (lane & 15) < 12;
-  const double* pm = sN + ((rw ? (N - 1) : m) - LA - h) * kSlot + i * kCol;  // pair p: + (LA-2p-1)*kSlot + c
+  const int ib = chain_row_t(lane);
+  const double* pm = sN + ((rw ? (N - 1) : m) - LA - h) * kSlot + (rw ? chain_gap(m) : 0) + ib * kCol;  // pair p: + (LA-2p-1)*kSlot + c
   double* px = sX + ((rw ? N : m) - LA) * 12 + i;                             // step t: + (LA-t)*12
   const double* pr = px - h * 12;                                             // pair p: + (LA-2p-1)*12
   double* dump = sDump + i;
@@ -214,7 +240,7 @@ __device__ __forceinline__ void chain_forward(const double* sN, double* sX, doub
   const int i = ((lane & 15) < 12) ? (lane & 15) : 11;
   const bool rw = (lane & 16) != 0;
   const bool wr = (lane < 32) && ((lane & 15) < 12);
-  const double* pm = sN + (rw ? m * kSlot : 0) + i;  // step t: + (t-1)*kSlot + c*kCol
+  const double* pm = sN + (rw ? m * kSlot + chain_gap(m) : 0) + i;  // step t: + (t-1)*kSlot + c*kCol
   double* px = sX + (rw ? (m + 1) * 12 : 0) + i;     // step t: + t*12 (t = 0: the chain's first vector)
   double* ps_early = wr ? px : sDump + i;            // stores of steps t < LB
   double* ps_late = (wr && !rw) ? px : sDump + i;    // stores of steps LB <= t < LA (chain A only)
@@ -270,7 +296,8 @@ __device__ __forceinline__ void chain_backward(const double* sN, double* sX, dou
   const bool wr = (lane < 32) && ((lane & 15) < 12);
   // both chains walk downwards: step t reads slot (top - t) and vector position (top - t); addressed from the lowest
   // one so that every immediate offset is non-negative
-  const double* pm = sN + ((rw ? (N - 1) : m) - LA) * kSlot + i * kCol;  // step t: + (LA-t)*kSlot + c
+  const int ib = chain_row_t(lane);
+  const double* pm = sN + ((rw ? (N - 1) : m) - LA) * kSlot + (rw ? chain_gap(m) : 0) + ib * kCol;  // step t: + (LA-t)*kSlot + c
   double* px = sX + ((rw ? N : m) - LA) * 12 + i;                         // step t: + (LA-t)*12
   double* ps_early = wr ? px : sDump + i;            // steps t <= LB
   double* ps_late = (wr && !rw) ? px : sDump + i;    // steps t > LB (chain A only)

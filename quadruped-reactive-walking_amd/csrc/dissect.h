@@ -34,12 +34,15 @@ constexpr int kFillStride = 148;     // doubles between consecutive E_k (dense 1
                                      // a wavefront hit disjoint LDS banks in the column access of phase 1)
 constexpr int kDisRootRhs = 34, kDisRootX = 35;  // vector positions of step 16: right-hand side / solution
 constexpr int kDisRightPos = 17;     // first vector position of the right half (its dummy step: always zero)
-constexpr int kDisRightSlot = 15;    // first chain slot of the right half (its dummy step's coupling: always zero; also the
-                                     // slot the left half's idle chain reads in its discarded last step)
+constexpr int kDisRightSlot = 15;    // first chain slot of the right half (its dummy step's coupling: always zero)
+constexpr int kDisRightBase = chain_slot(kDisRightSlot, 8);  // its offset in sN = the left half's slot 15 (what the left half's idle
+                                                             // chain reads in its discarded last step); each half addresses its
+                                                             // slots with chain_slot(s, 8) from its own base (chain_sweep.h)
 
-// LDS of one instance: 81 360 bytes, two instances per compute unit (160 KB).
+// LDS of one instance: 81 360 bytes, two instances per compute unit (160 KB); 83 536 with -DQRW_BANK_FREE_LAYOUT=1 (chain_sweep.h).
 struct alignas(16) MpcLdsDis {
-  double sN[30 * kSlot];                 // chain matrices: left half slots 0..14, zero slot 15 (= right slot 0), right 16..29
+  double sN[kDisRightBase + chain_lds_doubles(15, 8)];  // chain matrices: left half slots 0..14, right half from kDisRightBase
+                                         // (its slot 0: the zero matrix both halves start their chains from)
   double sFill[15 * kFillStride + 144];  // E_k, fill index f = k - 8 (k = 8..15), k - 9 (k = 17..24).  MUST follow sN: the
                                          // right half's idle read (its slot 15) lands in E_8 -- finite, result discarded
   double sX[36 * 12];                    // vectors: left half positions 0..16 (16: zeros), right 17..33 (17, 33: zeros), 34, 35
@@ -53,7 +56,7 @@ struct alignas(16) MpcLdsDis {
   unsigned long long sBal[2];
   double sPre[8];
 };
-static_assert(sizeof(MpcLdsDis) <= 81920, "two N = 32 instances per compute unit need <= 80 KB each");
+static_assert(sizeof(MpcLdsDis) <= (QRW_BANK_FREE_LAYOUT ? 84 * 1024 : 81920), "two N = 32 instances per compute unit need <= 80 KB each");
 static_assert(36 * 12 + 12 * 16 >= 4 * 144, "the four hand-off buffers of the factor phase overlay sX + sC");
 static_assert(32 * kDisWSz >= (16 / 2 + 2) * 12, "the sweeps' dump area overlays sW");
 
@@ -140,12 +143,12 @@ __device__ __forceinline__ void dis_factorize(LdsT& L, double dt, int tid, int k
   const double sA = down ? 0.0 : 1.0, sB = down ? 1.0 : 0.0;
   const double hi6 = (i >= 6) ? 1.0 : 0.0, lo6 = (i < 6) ? 1.0 : 0.0;
   double* hand = L.sX + (2 * wv + (rowB ? 1 : 0)) * 144;
-  double* slots = L.sN + wv * kDisRightSlot * kSlot;
+  double* slots = L.sN + wv * kDisRightBase;
   double* pG = L.sFill + ((wv == 0) ? 0 : 15) * kFillStride;  // home of this wavefront's fill block G between the rounds
   double R[12];
 #pragma unroll
   for (int c = 0; c < 12; c++) R[c] = 0.0;
-  int prev_slot = kDisRightSlot - wv * kDisRightSlot;  // the zero slot (absolute slot 15) until the chain has made a matrix
+  int prev_off = kDisRightBase - wv * kDisRightBase;  // offset of the zero matrix (the right half's slot 0) until the chain has made one
   {
     double G[12];
 #pragma unroll
@@ -208,7 +211,7 @@ __device__ __forceinline__ void dis_factorize(LdsT& L, double dt, int tid, int k
       const double* WS = &L.sW[ks * kDisWSz];
       double term[12], nn[12];  // nn: row i of the negated coupling matrix this chain made in its previous round
 #pragma unroll
-      for (int c = 0; c < 12; c++) nn[c] = slots[prev_slot * kSlot + c * kCol + i];
+      for (int c = 0; c < 12; c++) nn[c] = slots[prev_off + c * kCol + i];
 #pragma unroll
       for (int c = 0; c < 6; c++) term[c] = -omS[c] * nn[c] - sA * (dt * omS[c]) * nn[c + 6];
 #pragma unroll
@@ -301,7 +304,7 @@ __device__ __forceinline__ void dis_factorize(LdsT& L, double dt, int tid, int k
         // down -> 32 - kk, up -> kk - 9
         const int slot = (wv == 0) ? (down ? 23 - kk : kk) : (down ? 32 - kk : kk - 9);
 #pragma unroll
-        for (int c = 0; c < 12; c++) slots[slot * kSlot + c * kCol + i] = nx[c];
+        for (int c = 0; c < 12; c++) slots[chain_slot(slot, 8) + c * kCol + i] = nx[c];
       }
       {  // fill of the next step of this chain (or of the half root): G <- (negated coupling) G
         double Gn[12], G[12];
@@ -313,7 +316,7 @@ __device__ __forceinline__ void dis_factorize(LdsT& L, double dt, int tid, int k
           for (int c = 0; c < 12; c++) pG[i * 12 + c] = Gn[c];
         }
       }
-      if (active) prev_slot = (wv == 0) ? (down ? 23 - kk : kk) : (down ? 32 - kk : kk - 9);
+      if (active) prev_off = chain_slot((wv == 0) ? (down ? 23 - kk : kk) : (down ? 32 - kk : kk - 9), 8);
     }
     __syncthreads();
   }
@@ -368,7 +371,7 @@ __device__ __forceinline__ void dis_solve(LdsT& L, const double (&rX)[3], RowFn&
     for (int t = 0; t < 3; t++) px[t] = rX[t];
   }
   asm volatile("" ::: "memory");  // a half's right-hand side is written by the wavefront that sweeps it
-  chain_forward_paired<16>(L.sN + wv * kDisRightSlot * kSlot, L.sX + wv * kDisRightPos * 12, dump, lane);
+  chain_forward_paired<16>(L.sN + wv * kDisRightBase, L.sX + wv * kDisRightPos * 12, dump, lane);
   asm volatile("" ::: "memory");
   Mark(3);
   // ---- phase 1: v = Delta^-1 u (kept in registers), fill contributions d = E' u into sC
@@ -432,7 +435,7 @@ __device__ __forceinline__ void dis_solve(LdsT& L, const double (&rX)[3], RowFn&
   }
   asm volatile("" ::: "memory");
   Mark(4);
-  chain_backward_paired<16>(L.sN + wv * kDisRightSlot * kSlot, L.sX + wv * kDisRightPos * 12, dump, lane);
+  chain_backward_paired<16>(L.sN + wv * kDisRightBase, L.sX + wv * kDisRightPos * 12, dump, lane);
   __syncthreads();
   Mark(5);
 }

@@ -48,7 +48,7 @@ constexpr int kWSz = 36;
 template <int NW>
 struct alignas(16) MpcLdsT {
   static constexpr int S = 16 * NW;
-  double sN[S * kSlot];      // S-1 chain matrices (+1 slot only ever read by the idle chain's discarded step)
+  double sN[chain_lds_doubles(S, S / 2)];  // S-1 chain matrices (+1 slot only ever read by the idle chain's discarded step); chain_slot()
   double sX[(S + 2) * 12];   // step k at chain_pos(k); position N is a zero vector, N+1 padding for the idle step
   double sDump[(S / 2 + 2) * 12];  // sink for the sweeps' masked stores
   double sE[S * 12];     // step k <-> k+-1 exchange across wavefronts
@@ -366,7 +366,7 @@ __device__ __forceinline__ void chain_factorize(LdsT& L, int N, double dt, int t
       if (active && lane < 32 && (lane & 15) < 12) {
         const int slot = rowB ? (mroot + N - 2 - (kk - 1)) : kk;
 #pragma unroll
-        for (int c = 0; c < 12; c++) L.sN[slot * kSlot + c * kCol + i] = nx[c];
+        for (int c = 0; c < 12; c++) L.sN[chain_slot(slot, mroot) + c * kCol + i] = nx[c];
       }
 #pragma unroll
       for (int c = 0; c < 12; c++) nn[c] = active ? nx[c] : nn[c];
@@ -717,14 +717,14 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     kx = dis_pos(k);
     kpx = dis_pos(kp);
     for (int e = tid; e < 36 * 12; e += T) L.sX[e] = 0.0;
-    for (int e = tid; e < kSlot; e += T) L.sN[kDisRightSlot * kSlot + e] = 0.0;
+    for (int e = tid; e < kSlot; e += T) L.sN[kDisRightBase + e] = 0.0;
     for (int e = tid; e < 15 * kFillStride + 144; e += T) L.sFill[e] = 0.0;
     if (tid < 48) (&L.sEb[0][0])[tid] = 0.0;
   } else {
     kx = act ? chain_pos(k, N >> 1, N) : k;
     kpx = act ? chain_pos(kp, N >> 1, N) : k;
     if (tid < 24) L.sX[N * 12 + tid] = 0.0;
-    for (int e = tid; e < kSlot; e += T) L.sN[(16 * NW - 1) * kSlot + e] = 0.0;
+    for (int e = tid; e < kSlot; e += T) L.sN[chain_slot(16 * NW - 1, N >> 1) + e] = 0.0;
   }
 
   // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
@@ -1790,11 +1790,11 @@ int mpc_sequence_launch(const MpcArgs& a, hipStream_t stream) {
 // sweeps of chain_sweep.h in the production LDS layout and the in-register Gauss-Jordan inverse -------------------------
 namespace qrw {
 __global__ void sweeps_selftest_kernel(const double* M, const double* r, const double* G, double* out, double* ginv) {
-  __shared__ __attribute__((aligned(16))) double sN[16 * kSlot];
+  __shared__ __attribute__((aligned(16))) double sN[chain_lds_doubles(16, 8)];
   __shared__ double sX[18 * 12];
   __shared__ double sDump[10 * 12];
   const int lane = threadIdx.x;
-  for (int e = lane; e < 16 * kSlot; e += 64) sN[e] = M[e];
+  for (int e = lane; e < chain_lds_doubles(16, 8); e += 64) sN[e] = M[e];
   for (int e = lane; e < 18 * 12; e += 64) sX[e] = r[e];
   __syncthreads();
   chain_forward<16>(sN, sX, sDump, 16, lane);
@@ -1815,11 +1815,11 @@ __global__ void sweeps_selftest_kernel(const double* M, const double* r, const d
 
 int sweeps_selftest(double* max_err) {
   constexpr int N = 16, m = N / 2;
-  static double hM[16 * kSlot], hr[18 * 12], hout[18 * 12], hG[288], hGi[288];
-  for (int e = 0; e < 16 * kSlot; e++) hM[e] = 0.0;
+  static double hM[chain_lds_doubles(16, 8)], hr[18 * 12], hout[18 * 12], hG[288], hGi[288];
+  for (int e = 0; e < chain_lds_doubles(16, 8); e++) hM[e] = 0.0;
   for (int s = 0; s < N - 1; s++)
     for (int i = 0; i < 12; i++)
-      for (int c = 0; c < 12; c++) hM[s * kSlot + c * kCol + i] = 0.25 * sin(0.37 * (s * 144 + i * 12 + c) + 1.0);
+      for (int c = 0; c < 12; c++) hM[chain_slot(s, m) + c * kCol + i] = 0.25 * sin(0.37 * (s * 144 + i * 12 + c) + 1.0);
   for (int e = 0; e < 18 * 12; e++) hr[e] = 0.0;
   for (int k = 0; k < N; k++)
     for (int i = 0; i < 12; i++) hr[chain_pos(k, m, N) * 12 + i] = cos(0.11 * (k * 12 + i));
@@ -1827,7 +1827,7 @@ int sweeps_selftest(double* max_err) {
     for (int i = 0; i < 12; i++)
       for (int c = 0; c < 12; c++) hG[w * 144 + i * 12 + c] = ((i == c) ? 4.0 + w : 0.0) + 0.3 * sin(1.7 * (w * 144 + i * 12 + c));
   // host evaluation of the same recursions (forward, then backward on its result)
-  auto Mat = [&](int slot, int i, int c) { return hM[slot * kSlot + c * kCol + i]; };
+  auto Mat = [&](int slot, int i, int c) { return hM[chain_slot(slot, m) + c * kCol + i]; };
   double u[N][12], t[12];
   for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) u[k][i] = hr[chain_pos(k, m, N) * 12 + i];
   for (int k = 1; k < m; k++) for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(k - 1, i, c) * u[k - 1][c]; u[k][i] = s; }
@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(128) void dissect_selftest_kernel(const double* om,
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int k = 16 * wv + (lane >> 2), j = lane & 3;
   for (int e = tid; e < 36 * 12; e += 128) L.sX[e] = 0.0;
-  for (int e = tid; e < kSlot; e += 128) L.sN[kDisRightSlot * kSlot + e] = 0.0;
+  for (int e = tid; e < kSlot; e += 128) L.sN[kDisRightBase + e] = 0.0;
   for (int e = tid; e < 15 * kFillStride + 144; e += 128) L.sFill[e] = 0.0;
   if (tid < 48) (&L.sEb[0][0])[tid] = 0.0;
   for (int e = tid; e < 32 * 12; e += 128) { L.sOm[e] = om[e]; L.sDg[e] = dg[e]; }

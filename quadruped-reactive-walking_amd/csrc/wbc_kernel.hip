@@ -26,6 +26,18 @@
 #include "controller_glue.h"
 #include "qrw_kernels.h"
 
+// Diagnostic build (-DQRW_PROFILE_WBC): shader-clock stamps of wbc_kernel's phases, per workgroup (lane 0), read back by
+// qrw_wbc_get_phase_cycles -- scripts/gpu_wbc_phases.py, profiles/r4_wbc_phase_cycles.txt
+#ifdef QRW_PROFILE_WBC
+__device__ unsigned long long g_wbc_ph[16 * 8192];
+#define WPH(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_wbc_ph[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int qrw_wbc_get_phase_cycles(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wbc_ph), (size_t)n_blocks * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define WPH(i)
+#endif
+
 namespace qrw {
 
 namespace {
@@ -249,6 +261,7 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
   const double eps_prim_inf = 1e-4, eps_dual_inf = 1e-4;
   // the warm-start state is read unconditionally, together with the flag that says whether it counts: one round trip
   // to HBM instead of two (padding quads read instance 0's)
+  WPH(3);
   const double init_flag = st[kWsInit];
   double x[3], z[5], y[5], rho = st[kWsRho], gprev[3];
 #pragma unroll
@@ -317,6 +330,7 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
     ct = limit_scaling(ct);
     cs *= 1.0 / ct;
   }
+  WPH(4);
   const double cinv = 1.0 / cs;
   double iD[3], iE[5], ls[5], us[5];
 #pragma unroll
@@ -542,6 +556,10 @@ __device__ void qp_solve(const QpIo& io, double* st, int j, bool valid, double s
       }
     }
   }
+  WPH(5);
+#ifdef QRW_PROFILE_WBC
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_wbc_ph[blockIdx.x * 16 + 8] = (unsigned long long)iter;
+#endif
   if (iter > max_iter) iter = max_iter;
   if (status == kStatusUnsolved) {
     const bool pok = pri_res < 10 * eps_abs + 10 * eps_rel * last_np;
@@ -609,6 +627,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   const int b = blockIdx.x * 16 + (lane >> 2);
   const bool valid = b < a.B;
   const int bb = valid ? b : 0;
+  WPH(0);
   const LegC C = leg_consts(j);
   double* st = a.st + (size_t)bb * kWbcStItems;
 
@@ -757,6 +776,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
     ks *= contact;
     if (valid) st[kWsKsc + j] = ks;
   }
+  WPH(1);
   const LegKin K = leg_kinematics(C, q);
   // ---- fixed-base foot velocity and classical acceleration with zero joint acceleration
   const V3 vf = dq[0] * K.J0 + dq[1] * K.J1 + dq[2] * K.J2;
@@ -875,6 +895,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
 #pragma unroll
     for (int i = 0; i < 6; i++) pk[(21 + i) * 64] = gamma[i];
   }
+  WPH(2);
   QpIo io;
   qp_build(Aj, gamma, fc, j, io);
   double sol[3];
@@ -882,6 +903,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   // re-read after the solve (not carried across it): joint angles and base quaternion for the second evaluation of the
   // leg kinematics, and the operands of the fused result / security check
   qp_solve(io, st, j, valid, sol, it, stt);
+  WPH(6);
   double q2[3], qq[4], c_err0 = 0.0, c_qf[3] = {0.0, 0.0, 0.0}, c_vs[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int t = 0; t < 3; t++) q2[t] = qv[7 + 3 * j + t];
@@ -1004,6 +1026,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
       if (j == 0 && a.c_err) a.c_err[bb] = err;
     }
   }
+  WPH(7);
 }
 
 // pseudoInverse<> of the reference (include/qrw/InvKin.hpp:60-66: JacobiSVD, V diag(1/s_i if s_i > eps max(r,c) s_0 else 0) U^H)
