@@ -267,11 +267,14 @@ def main():
             pipe.drain()  # the last all-gather belongs to the timed work
         barrier()
         el = time.perf_counter() - t0
+        local_el.append(el)  # this rank's own clock, before the maximum over the ranks (a straggler GPU shows in per_rank)
         if multi:
             tt = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el
+
+    local_el = []
 
     ranks_seen = [0]
     if multi:
@@ -338,6 +341,22 @@ def main():
         out["handle_create_s"] = t_create
         out["device_ordinal"] = local_rank
         out["shard_first_instance"] = shard_rank * B
+    if multi:
+        # what a first scaling run is judged on, from EVERY rank (rank 0's own figures alone would hide a straggler GPU)
+        mine = [float(rank), float(local_rank), float(shard_rank * B), local_el[0], local_el[1] if len(local_el) > 1 else float("nan"),
+                float(mpc_ms.mean()) if not stub else float("nan"), float(wbc_ms.mean()) if not stub else float("nan"),
+                float(iters.mean()) if not stub else float("nan"), float(len(ranks_seen)),
+                (1.0 if gather_ok else 0.0) if gather_ok is not None else float("nan")]
+        tv = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(tv) for _ in range(world)]
+        dist.all_gather(allv, tv)
+        nn = lambda x: None if x != x else x
+        out["per_rank"] = [
+            {"rank": int(v[0]), "device_ordinal": int(v[1]), "shard_first_instance": int(v[2]), "timed_region_s": float(v[3]),
+             "steps_per_s": B * K / float(v[3]), "no_collective_steps_per_s": nn(B * K / float(v[4]) if float(v[4]) == float(v[4]) else float("nan")),
+             "launch_ms_mean": nn(float(v[5])), "wbc_ms_mean": nn(float(v[6])), "mean_admm_iters": nn(float(v[7])),
+             "ranks_seen": int(v[8]), "gathered_block_check": (None if float(v[9]) != float(v[9]) else bool(v[9]))}
+            for v in (t.cpu().tolist() for t in allv)]
     if rank == 0 and world == 1 and not stub:
         out["mpc_solves_per_s"] = B * K / (mpc_ms.sum() * 1e-3)
         out["wbc_steps_per_s"] = B * K / (wbc_ms.sum() * 1e-3)

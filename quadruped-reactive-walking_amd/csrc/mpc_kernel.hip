@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "chain_sweep.h"
 #include "dissect.h"
@@ -1813,10 +1814,26 @@ __global__ void sweeps_selftest_kernel(const double* M, const double* r, const d
     for (int c = 0; c < 12; c++) ginv[which * 144 + i * 12 + c] = m[c];
 }
 
+namespace {
+// device buffers and the stream of a self-test: every allocation checked, released on every path; a private non-blocking
+// stream, so that a self-test neither waits for nor stalls what other streams of the process have queued
+struct SelfTestBuf {
+  void* p = nullptr;
+  ~SelfTestBuf() { if (p) hipFree(p); }
+  bool alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess; }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct SelfTestStream {
+  hipStream_t s = nullptr;
+  ~SelfTestStream() { if (s) hipStreamDestroy(s); }
+  bool create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess; }
+};
+}  // namespace
+
 int sweeps_selftest(double* max_err) {
   constexpr int N = 16, m = N / 2;
-  static double hM[chain_lds_doubles(16, 8)], hr[18 * 12], hout[18 * 12], hG[288], hGi[288];
-  for (int e = 0; e < chain_lds_doubles(16, 8); e++) hM[e] = 0.0;
+  std::vector<double> hMv(chain_lds_doubles(16, 8), 0.0), hrv(18 * 12), houtv(18 * 12), hGv(288), hGiv(288);
+  double *hM = hMv.data(), *hr = hrv.data(), *hout = houtv.data(), *hG = hGv.data(), *hGi = hGiv.data();
   for (int s = 0; s < N - 1; s++)
     for (int i = 0; i < 12; i++)
       for (int c = 0; c < 12; c++) hM[chain_slot(s, m) + c * kCol + i] = 0.25 * sin(0.37 * (s * 144 + i * 12 + c) + 1.0);
@@ -1836,17 +1853,16 @@ int sweeps_selftest(double* max_err) {
   for (int i = 0; i < 12; i++) u[m][i] = t[i];
   for (int k = m - 1; k >= 0; k--) { for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(k, c, i) * u[k + 1][c]; t[i] = s; } for (int i = 0; i < 12; i++) u[k][i] = t[i]; }
   for (int k = m + 1; k < N; k++) { for (int i = 0; i < 12; i++) { double s = u[k][i]; for (int c = 0; c < 12; c++) s += Mat(m + N - 2 - (k - 1), c, i) * u[k - 1][c]; t[i] = s; } for (int i = 0; i < 12; i++) u[k][i] = t[i]; }
-  double *dM, *dr, *dG, *dout, *dGi;
-  if (hipMalloc((void**)&dM, sizeof(hM)) != hipSuccess) return -1;
-  hipMalloc((void**)&dr, sizeof(hr)); hipMalloc((void**)&dG, sizeof(hG)); hipMalloc((void**)&dout, sizeof(hout));
-  hipMalloc((void**)&dGi, sizeof(hGi));
-  hipMemcpy(dM, hM, sizeof(hM), hipMemcpyHostToDevice); hipMemcpy(dr, hr, sizeof(hr), hipMemcpyHostToDevice);
-  hipMemcpy(dG, hG, sizeof(hG), hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(sweeps_selftest_kernel, dim3(1), dim3(64), 0, 0, dM, dr, dG, dout, dGi);
-  hipError_t e = hipDeviceSynchronize();
-  hipMemcpy(hout, dout, sizeof(hout), hipMemcpyDeviceToHost); hipMemcpy(hGi, dGi, sizeof(hGi), hipMemcpyDeviceToHost);
-  hipFree(dM); hipFree(dr); hipFree(dG); hipFree(dout); hipFree(dGi);
-  if (e != hipSuccess) return -2;
+  SelfTestBuf bM, br, bG, bout, bGi;
+  SelfTestStream st;
+  const size_t nM = hMv.size() * sizeof(double), nr = hrv.size() * sizeof(double), nG = hGv.size() * sizeof(double);
+  if (!bM.alloc(nM) || !br.alloc(nr) || !bG.alloc(nG) || !bout.alloc(nr) || !bGi.alloc(nG) || !st.create()) return -1;
+  hipMemcpyAsync(bM.p, hM, nM, hipMemcpyHostToDevice, st.s); hipMemcpyAsync(br.p, hr, nr, hipMemcpyHostToDevice, st.s);
+  hipMemcpyAsync(bG.p, hG, nG, hipMemcpyHostToDevice, st.s);
+  hipLaunchKernelGGL(sweeps_selftest_kernel, dim3(1), dim3(64), 0, st.s, bM.as<double>(), br.as<double>(), bG.as<double>(), bout.as<double>(),
+                     bGi.as<double>());
+  hipMemcpyAsync(hout, bout.p, nr, hipMemcpyDeviceToHost, st.s); hipMemcpyAsync(hGi, bGi.p, nG, hipMemcpyDeviceToHost, st.s);
+  if (hipStreamSynchronize(st.s) != hipSuccess) return -2;
   double me = 0.0;
   for (int k = 0; k < N; k++) for (int i = 0; i < 12; i++) me = fmax(me, fabs(hout[chain_pos(k, m, N) * 12 + i] - u[k][i]) / 8.0);
   for (int w = 0; w < 2; w++)  // G * G^-1 = I
@@ -1900,8 +1916,10 @@ __global__ __launch_bounds__(128) void dissect_selftest_kernel(const double* om,
 int dissect_selftest(double* max_err) {
   constexpr int N = 32, n = 12, D = N * n;
   const double dt = 0.02;
-  static double om[N * 12], dg[N * 12], W[N * 36], r[2 * D], xd[2 * D];
-  static double K[D * D], rhs[2][D];
+  // (heap, not function-static: concurrent callers must not share them)
+  std::vector<double> omv(N * 12), dgv(N * 12), Wv(N * 36), rv(2 * D), xdv(2 * D), Kv((size_t)D * D), rhsv(2 * D);
+  double *om = omv.data(), *dg = dgv.data(), *W = Wv.data(), *r = rv.data(), *xd = xdv.data(), *K = Kv.data();
+  double (*rhs)[D] = reinterpret_cast<double (*)[D]>(rhsv.data());
   // synthetic data with the kernel's structure and spread of magnitudes: omega_D of the dynamics rows, K^-1 blocks, cost diagonal
   for (int k = 0; k < N; k++) {
     for (int i = 0; i < 12; i++) {
@@ -1963,17 +1981,17 @@ int dissect_selftest(double* max_err) {
       for (int cc = c + 1; cc < D; cc++) s_ -= K[(size_t)c * D + cc] * rhs[q][cc];
       rhs[q][c] = s_ / K[(size_t)c * D + c];
     }
-  double *dom, *ddg, *dW, *dr, *dx;
-  if (hipMalloc((void**)&dom, sizeof(om)) != hipSuccess) return -1;
-  hipMalloc((void**)&ddg, sizeof(dg)); hipMalloc((void**)&dW, sizeof(W)); hipMalloc((void**)&dr, sizeof(r)); hipMalloc((void**)&dx, sizeof(xd));
-  hipMemcpy(dom, om, sizeof(om), hipMemcpyHostToDevice); hipMemcpy(ddg, dg, sizeof(dg), hipMemcpyHostToDevice);
-  hipMemcpy(dW, W, sizeof(W), hipMemcpyHostToDevice); hipMemcpy(dr, r, sizeof(r), hipMemcpyHostToDevice);
-  hipMemset(dx, 0xFF, sizeof(xd));
-  hipLaunchKernelGGL(dissect_selftest_kernel, dim3(1), dim3(128), 0, 0, dom, ddg, dW, dr, dt, dx);
-  hipError_t e = hipDeviceSynchronize();
-  hipMemcpy(xd, dx, sizeof(xd), hipMemcpyDeviceToHost);
-  hipFree(dom); hipFree(ddg); hipFree(dW); hipFree(dr); hipFree(dx);
-  if (e != hipSuccess) return -2;
+  SelfTestBuf bom, bdg, bW, br, bx;
+  SelfTestStream st;
+  const size_t n12 = omv.size() * sizeof(double), nW = Wv.size() * sizeof(double), n2D = rv.size() * sizeof(double);
+  if (!bom.alloc(n12) || !bdg.alloc(n12) || !bW.alloc(nW) || !br.alloc(n2D) || !bx.alloc(n2D) || !st.create()) return -1;
+  hipMemcpyAsync(bom.p, om, n12, hipMemcpyHostToDevice, st.s); hipMemcpyAsync(bdg.p, dg, n12, hipMemcpyHostToDevice, st.s);
+  hipMemcpyAsync(bW.p, W, nW, hipMemcpyHostToDevice, st.s); hipMemcpyAsync(br.p, r, n2D, hipMemcpyHostToDevice, st.s);
+  hipMemsetAsync(bx.p, 0xFF, n2D, st.s);
+  hipLaunchKernelGGL(dissect_selftest_kernel, dim3(1), dim3(128), 0, st.s, bom.as<double>(), bdg.as<double>(), bW.as<double>(), br.as<double>(),
+                     dt, bx.as<double>());
+  hipMemcpyAsync(xd, bx.p, n2D, hipMemcpyDeviceToHost, st.s);
+  if (hipStreamSynchronize(st.s) != hipSuccess) return -2;
   double me = 0.0, scale = 0.0;
   for (int q = 0; q < 2; q++) for (int c = 0; c < D; c++) scale = fmax(scale, fabs(rhs[q][c]));
   for (int q = 0; q < 2; q++)

@@ -855,6 +855,7 @@ extern "C" int qrw_get_base_inertia_diag(qrw_handle h, double* h_Y6) {
 extern "C" int qrw_selftest_sweeps(double* max_err) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_selftest_sweeps: no HIP device");
+  std::lock_guard<std::mutex> lock(g_kat_mutex);  // one self-test at a time (qrw_create's known-answer check takes the same lock)
   const int rc = qrw::sweeps_selftest(max_err);
   if (rc != 0) return rc;
   double derr = 0.0;

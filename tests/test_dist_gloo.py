@@ -104,6 +104,12 @@ def test_bench_own_multi_rank_branch_two_ranks_gloo():
     assert c["ranks_seen"] == [0, 1] and c["gathered_block_check"] is True
     assert c["bytes_per_rank_per_step"] == 8 * 12 * 8 and c["no_collective_steps_per_s"] > 0
     assert line["value"] > 0 and abs(line["value"] - 2 * 8 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    # every rank reports its own clock and checks (a straggler GPU must show in the line, not only rank 0's figures)
+    pr = line["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and [p["shard_first_instance"] for p in pr] == [0, 8]
+    assert all(p["ranks_seen"] == 2 and p["gathered_block_check"] is True and p["steps_per_s"] > 0 and
+               p["no_collective_steps_per_s"] > 0 for p in pr)
+    assert max(p["timed_region_s"] for p in pr) <= line["ms_per_step"] * 3e-3 * (1 + 1e-9)
 
 
 def test_bench_refuses_flag_launcher_mismatch():
@@ -169,3 +175,4 @@ def test_bench_own_multi_rank_branch_eight_ranks_gloo():
     c = line["collective"]
     assert c["ranks_seen"] == list(range(8)) and c["gathered_block_check"] is True
     assert abs(line["value"] - 8 * 4 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert [p["rank"] for p in line["per_rank"]] == list(range(8)) and all(p["gathered_block_check"] for p in line["per_rank"])
