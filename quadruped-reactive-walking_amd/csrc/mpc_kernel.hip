@@ -411,13 +411,12 @@ __device__ __forceinline__ unsigned q_load(const unsigned* p) { return __hip_ato
 // 2 s without a single finished task means the queue is really stuck.  The counter is read only when the 2 s have passed.
 struct SeqGiveUp {
   unsigned long long t0;
-  unsigned last, limit;
+  unsigned last;
   const unsigned* prog;
-  __device__ __forceinline__ SeqGiveUp(const unsigned* p, unsigned ticks = 0u)
-      : t0(__builtin_amdgcn_s_memrealtime()), last(q_load(p)), limit(ticks ? ticks : 200000000u), prog(p) {}
+  __device__ __forceinline__ SeqGiveUp(const unsigned* p) : t0(__builtin_amdgcn_s_memrealtime()), last(q_load(p)), prog(p) {}
   __device__ __forceinline__ bool expired() {
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    if (now - t0 <= (unsigned long long)limit) return false;
+    if (now - t0 <= 200000000ull) return false;
     const unsigned p = q_load(prog);
     if (p != last) { last = p; t0 = now; return false; }
     return true;
@@ -528,11 +527,11 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // have finished, which the takers see (`finished` == B) and leave.
 //   pre_ctr words: qrw_kernels.h (kPre*Word)
 constexpr int kPreHead = kPreTicketWord, kPreTail = kPreParksWord, kPreDone = kPreDoneWord, kPreErr = kPreErrWord, kPreProgress = kPreProgressWord;
-// error word of the time-sliced launch (1, 3, 4: a taker gave up waiting; 2: a level's queue overran) -- in pre_ctr for the
-// other workgroups of the launch and the host's getters, and in a host-mapped word that qrw_mpc_solve reads on entry
+// error word of the time-sliced launch (1, 3, 4: a taker gave up waiting; 2: a level's queue overran; 9: set by the host before
+// the launch, tests only: every queue-fed workgroup leaves at once).  mpc_pre_error_flush copies it to a host-mapped word behind
+// the launch (a store to host memory from inside this kernel, cold as it is, cost the N = 32 instantiation 1 % -- A/B in round 4)
 __device__ __forceinline__ void pre_set_error(const MpcArgs& a, unsigned code) {
   __hip_atomic_store(&a.pre_ctr[kPreErr], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.pre_err_host) __hip_atomic_store(a.pre_err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <int NW>
 __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
@@ -540,7 +539,7 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
   if (tid == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket < (unsigned)a.pre_cap) {
-      SeqGiveUp clock(&a.pre_ctr[kPreProgress], a.giveup_ticks);
+      SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
       bool gated = false;
       for (;;) {
         if (q_load(&a.pre_ctr[kPreTail]) > ticket) { gated = true; break; }
@@ -1710,6 +1709,16 @@ int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream) {
   const unsigned blocks = (unsigned)a.B * (unsigned)a.pre_cmax;
   if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false, true>), dim3(blocks), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// behind a time-sliced launch, on its stream: the launch's error word, if set, into a host-mapped word (sticky: the host clears it)
+__global__ void mpc_pre_error_flush_kernel(const unsigned* pre_ctr, unsigned* host_word) {
+  const unsigned code = pre_ctr[kPreErr];
+  if (code != 0u) __hip_atomic_store(host_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int mpc_pre_error_flush(const unsigned* pre_ctr, unsigned* host_word, hipStream_t stream) {
+  hipLaunchKernelGGL(mpc_pre_error_flush_kernel, dim3(1), dim3(1), 0, stream, pre_ctr, host_word);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -60,7 +60,7 @@ struct qrw_handle_s {
   int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0, pre_levels = 1, pre_bin = 200;
   unsigned* pre_err_host = nullptr;  // pinned, host-mapped: the kernel's give-up code of a time-sliced launch (read on entry of the next)
   unsigned* pre_err_dev = nullptr;   // its device address
-  unsigned giveup_ticks = 0;         // give-up clock in 100 MHz ticks (0: the kernel's default, 2 s)
+  bool force_giveup = false;         // tests (QRW_PREEMPT_FORCE_GIVEUP=1): every time-sliced launch starts with its error word set
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
@@ -329,8 +329,9 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
         return fail(-10, "qrw_create: hipHostMalloc of the time-sliced launch's error word");
       }
       h->pre_err_host[0] = 0u;
-      // tests: a short give-up clock (microseconds without any slice of the launch ending) forces the give-up path
-      if (const char* ge = getenv("QRW_PREEMPT_GIVEUP_US")) { const long us = atol(ge); if (us > 0 && us < 40000000) h->giveup_ticks = (unsigned)(us * 100); }
+      // tests: the launch starts with its error word set, so every queue-fed workgroup leaves at once ("somebody gave up
+      // already") and no parked solve is ever finished -- the state a queue that gave up leaves behind, without waiting 2 s for it
+      if (const char* ge = getenv("QRW_PREEMPT_FORCE_GIVEUP")) h->force_giveup = (ge[0] == '1');
     }
   }
   {  // known answer through the instantiation of mpc_solve_kernel this handle's qrw_mpc_solve will launch
@@ -391,7 +392,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
       char msg[256];
       snprintf(msg, sizeof(msg), "qrw_mpc_solve: an earlier time-sliced MPC launch of this handle gave up (code %u: %s); its unfinished "
                "instances hold NaN results and restart cold at the next call", code,
-               code == 2u ? "a priority level's queue overran" : "a workgroup waited for a parked solve without any slice ending");
+               code == 2u ? "a priority level's queue overran" : code == 9u ? "forced by QRW_PREEMPT_FORCE_GIVEUP" : "a workgroup waited for a parked solve without any slice ending");
       return fail(-12, msg);
     }
   }
@@ -409,14 +410,19 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
     a.pre_chunk = h->pre_chunk; a.pre_cmax = h->pre_cmax; a.pre_cap = h->cfg.batch * (h->pre_cmax - 1);
     a.pre_queue = h->pre_queue; a.pre_ctr = h->pre_ctr; a.pause_it = h->pause_it;
     a.pre_levels = h->pre_levels; a.pre_bin = h->pre_bin;
-    a.pre_err_host = h->pre_err_dev; a.giveup_ticks = h->giveup_ticks;
     HIP_OK(hipMemsetAsync(h->pre_queue, 0xFF, (size_t)a.pre_levels * a.pre_cap * sizeof(int), (hipStream_t)stream), "qrw_mpc_solve: queue reset");
     HIP_OK(hipMemsetAsync(h->pre_ctr, 0, qrw::kPreCtrWords * sizeof(unsigned), (hipStream_t)stream), "qrw_mpc_solve: counter reset");
     // a solve that a given-up queue left unfinished (never expected; qrw_mpc_get_stats reports it) must not leave the previous
     // call's numbers in the caller's buffer: NaN (all-ones bytes) until the finishing slice writes the result (~10 us per call)
     HIP_OK(hipMemsetAsync(d_out, 0xFF, (size_t)h->cfg.batch * 24 * (size_t)h->cfg.n_steps * sizeof(double), (hipStream_t)stream),
            "qrw_mpc_solve: result prefill");
-    if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0)
+    if (h->force_giveup) {
+      static const unsigned forced = 9u;
+      HIP_OK(hipMemcpyAsync(h->pre_ctr + qrw::kPreErrWord, &forced, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream),
+             "qrw_mpc_solve: forced give-up");
+    }
+    if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0 ||
+        qrw::mpc_pre_error_flush(h->pre_ctr, h->pre_err_dev, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   } else if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)

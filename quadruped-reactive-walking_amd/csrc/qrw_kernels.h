@@ -83,8 +83,6 @@ struct MpcArgs {
   int pre_levels;     // 1: one FIFO (plain round robin); > 1: level 0 = solves parked after their first slice, levels 1.. by the
                       // remaining iterations predicted from the residuals' decay (most first), pre_bin iterations per level
   int pre_bin;
-  unsigned* pre_err_host;  // optional: host-mapped copy of the error word (qrw_mpc_solve reads it on entry, without a device sync)
-  unsigned giveup_ticks;   // give-up clock of a waiting workgroup in 100 MHz ticks without observed progress (0: 2 s)
 };
 constexpr int kPreMaxLevels = 9;
 // pre_ctr words (one layout for the kernel, mpc_kernel.hip, and the host readers, qrw_api.hip): tickets drawn by takers, solves
@@ -95,6 +93,7 @@ constexpr int kPreLevelWord = 48;
 constexpr int kPreCtrWords = kPreLevelWord + 2 * kPreMaxLevels + 14;
 static_assert(kPreProgressWord < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
 int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
+int mpc_pre_error_flush(const unsigned* pre_ctr, unsigned* host_word, hipStream_t stream);  // error word -> host-mapped word, if set
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
 bool mpc_build_is_timing_experiment();

@@ -137,9 +137,9 @@ def test_tensor_on_wrong_device_or_dtype_is_refused():
 
 
 def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(synth_mod, oracle_mod, monkeypatch):
-    """A time-sliced MPC launch (N > 16) whose queue gives up -- forced here with a 20 us give-up clock: the queue-fed workgroups
-    leave before the first slice of 600 iterations (~2 ms) can end, so nobody finishes the parked solves -- must be visible where
-    the loop runs: (1) the unfinished results are NaN, (2) the controller's fourth error code stops those robots on the same
+    """A time-sliced MPC launch (N > 16) whose queue gives up -- forced here (QRW_PREEMPT_FORCE_GIVEUP=1: the launch starts with its
+    error word set, so the queue-fed workgroups leave at once, as they do when one of them has given up after 2 s without progress,
+    and nobody finishes the parked solves) -- must be visible where the loop runs: (1) the unfinished results are NaN, (2) the controller's fourth error code stops those robots on the same
     iteration (the reference's three `> limit` tests are blind to NaN, scripts/Controller.py:341-365), (3) the NEXT
     qrw_mpc_solve returns -12, once, without a device sync in between, (4) the call after it runs and starts the unfinished
     instances cold: same iteration count and result as an oracle that is re-created at that call's inputs."""
@@ -148,7 +148,7 @@ def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(sy
     from Controller import Controller_batch
 
     monkeypatch.setenv("QRW_PREEMPT_MIN_BATCH", "0")
-    monkeypatch.setenv("QRW_PREEMPT_GIVEUP_US", "20")
+    monkeypatch.setenv("QRW_PREEMPT_FORCE_GIVEUP", "1")
     B, N, Ng = 6, 32, 36
     sb = synth_mod.SyntheticBatch(B, N, N_gait=Ng, gaits=("trot",), seed0=424200)
     eng = qrw_hip.Batch(B, N, N_gait=Ng, T_gait=0.02 * N)
@@ -163,8 +163,8 @@ def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(sy
     assert "(-12)" in str(ei.value)
     with pytest.raises(qrw_hip.QrwError):
         eng.mpc_stats()                                    # the getter still says so too (it reads the launch's own counters)
-    monkeypatch.delenv("QRW_PREEMPT_GIVEUP_US")            # (the clock is read at creation: this handle keeps its 20 us)
-    # (4) the next call runs; with the same short clock it gives up again, so take a handle with the default clock and poke the
+    monkeypatch.delenv("QRW_PREEMPT_FORCE_GIVEUP")         # (read at creation: `eng` keeps forcing)
+    # (4) the next call runs; a forcing handle gives up again, so take a handle without the knob and poke the
     # aborted state into it: pause_it != 0 and the slots holding loop variables -- what the failed launch left behind
     eng2 = qrw_hip.Batch(B, N, N_gait=Ng, T_gait=0.02 * N)
     eng2.mpc_solve(x(d0), f(d0), 0)
@@ -182,7 +182,7 @@ def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(sy
         np.testing.assert_allclose(out[b].cpu().numpy(), m.get_latest_result(), rtol=1e-6, atol=1e-8)
 
     # (2) through the control loop: NaN forces -> code 4 -> security output on the same iteration
-    monkeypatch.setenv("QRW_PREEMPT_GIVEUP_US", "20")
+    monkeypatch.setenv("QRW_PREEMPT_FORCE_GIVEUP", "1")
     monkeypatch.setenv("QRW_PREEMPT_CHUNK", "200")         # (a solve from standstill may end within 600 iterations: cut at 200)
     q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
     ctl = Controller_batch(B, q_init, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=Ng)
