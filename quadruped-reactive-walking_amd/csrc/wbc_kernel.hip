@@ -8,7 +8,9 @@
 //   QPWBC::run                       src/QPWBC.cpp:310-390 (compute_matrices :481-498, update_PQ
 //                                    :520-537, call_solver :213-275 = OSQP 0.6.x, retrieve_result :277-297)
 //
-// Mapping: lane = 4*instance_in_wave + foot, i.e. ONE QUAD PER ROBOT INSTANCE and 16 instances per
+// Two kernels.  wbc16_kernel (round 4, below): SIXTEEN LANES per robot instance, the default for the full compute (27.9 us per
+// 4096 robots against 43.2).  wbc_kernel: one quad per instance; backs the stand-alone modes 1-3 and QRW_WBC16=0.
+// Mapping of wbc_kernel: lane = 4*instance_in_wave + foot, i.e. ONE QUAD PER ROBOT INSTANCE and 16 instances per
 // wavefront.  Each lane runs the kinematics / Newton-Euler recursion of its own leg; the base
 // wrench, the QP data and the 12-variable ADMM are shared inside the quad with DPP quad
 // permutes (no LDS).  The 20 friction-cone rows split 5 per lane and only touch that lane's 3
@@ -20,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/qrw_solo12_model.h"
 #include "qrw_device.h"
@@ -1029,6 +1032,600 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
   WPH(7);
 }
 
+// =====================================================================================================================
+// wbc16_kernel (round 4): the same wbc_controller.compute with SIXTEEN LANES PER ROBOT INSTANCE -- one 16-lane DPP row, four
+// instances per wavefront, B / 4 wavefronts (1024 at batch 4096: every SIMD of the chip; wbc_kernel's one quad per instance
+// fills a quarter of them and is bound by the issue rate of ONE wavefront's 18 k instructions, profiles/r4_wbc_phase_cycles.txt).
+//   lane of the row = 4 * foot + t.  t = 0, 1, 2: force variable x, y, z of that foot (12 QP variables on 12 lanes: the lane holds
+//   ITS row of H and of the KKT inverse, its x, D, g); t = 3: a pad lane.  The friction-cone rows of a foot sit on the lanes of
+//   its quad: row c = t on lane t ("slot A", c = 0..3), the fifth row (f_z <= 25) on the pad lane as well ("slot B"; every lane
+//   carries a slot B, only the pad lane's counts).
+//   * per-foot phases (leg kinematics, InvKin, Newton-Euler, QP data, epilogue): every lane of a quad runs its foot's arithmetic
+//     (the same instructions as wbc_kernel's one lane per foot; redundant, but no slower); sums over the feet are sums over the
+//     four quads of the row (row_xor4 / row_xor8 below, same association as quad_sum).
+//   * QP phases: a matrix-vector product with the 12 x 12 inverse is twelve v_fmac_f64_dpp with row_newbcast (the broadcast costs
+//     no instruction; wbc_kernel: 36 FMAs + 24 DPP moves per lane); the inverse itself is an in-register Gauss-Jordan across the
+//     row (as gj_invert12 of chain_sweep.h, for the padded lane numbering); the ten equilibration passes take a third of the
+//     instructions (12 instead of 36 norm entries per lane, one or two instead of five row scalings).
+//   Arithmetic: the per-foot phases, the QP data, the equilibration and the ADMM iteration evaluate wbc_kernel's expressions in
+//   wbc_kernel's order; the KKT inverse is eliminated with m[c] += m_P[c] * f instead of Ki - (f m_P[c]) d and a fast reciprocal:
+//   results agree with wbc_kernel to rounding (tests/test_gpu_wbc.py::test_wbc16_matches_the_quad_kernel), with the oracle as
+//   before.  QRW_WBC16=0 selects wbc_kernel for the full compute (the stand-alone modes always use it).
+namespace {
+
+template <int CTRL, int RM, int BM>
+__device__ __forceinline__ double dpp_d(double old, double v) {  // lanes the masks leave out keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, RM, BM, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, RM, BM, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int BM>
+__device__ __forceinline__ double dpp_all(double v) {  // every written lane has a source lane: no tied old value, no copy first
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, BM, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, BM, true);
+  return __hiloint2double(hi, lo);
+}
+// value of lane LANE of this lane's 16-lane row (row_newbcast; scripts/ubench/dpp_row_probe.hip checks these controls)
+template <int LANE>
+__device__ __forceinline__ double row_bcast(double v) { return dpp_all<0x150 + LANE, 0xF>(v); }
+// value of lane ^ 4 (row_shl:4 on banks 0, 2 + row_shr:4 on banks 1, 3; a bank = a quad of the row) / of lane ^ 8 (row_ror:8)
+__device__ __forceinline__ double row_xor4(double v) { const double t = dpp_all<0x104, 0x5>(v); return dpp_d<0x114, 0xF, 0xA>(t, v); }
+__device__ __forceinline__ double row_xor8(double v) { return dpp_all<0x128, 0xF>(v); }
+// over the four feet (quads) of a row, for a value that is uniform inside each quad; (q + q^1) + (q^2 + q^3) like quad_sum
+__device__ __forceinline__ double feet_sum(double v) { v += row_xor4(v); v += row_xor8(v); return v; }
+__device__ __forceinline__ double feet_max(double v) { v = fmax(v, row_xor4(v)); v = fmax(v, row_xor8(v)); return v; }
+__device__ __forceinline__ V3 feet_sum3(V3 v) { return mk(feet_sum(v.x), feet_sum(v.y), feet_sum(v.z)); }
+__device__ __forceinline__ double row_max(double v) { return feet_max(quad_max(v)); }  // over all 16 lanes
+
+// lane of the row that holds QP variable cb (0..11)
+#define QRW_VL(cb) (4 * ((cb) / 3) + (cb) % 3)
+// r + sum_cb m[cb] * x(lane of variable cb): the 12 x 12 row-times-vector product, broadcast folded into the FMAs
+__device__ __forceinline__ double row_matvec12(double r, double x, const double (&m)[12]) {
+  double a0 = r;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %5 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %6 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %11 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %12 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %1, %13 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(a0)
+      : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
+        "v"(m[9]), "v"(m[10]), "v"(m[11]));
+  return a0;
+}
+// sum_i A_i(any lane of quad Q) * coef_i, i = 0..5 in order: one entry of H = 0.1 A'A (QPWBC::compute_matrices)
+template <int Q>
+__device__ __forceinline__ double h_entry(const double (&A)[6], const double (&coef)[6]) {
+  double acc = 0.0;
+  asm("s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(coef[0]), "v"(coef[1]), "v"(coef[2]), "v"(coef[3]),
+        "v"(coef[4]), "v"(coef[5]), "n"(4 * Q));
+  return acc;
+}
+// one pivot of the in-register Gauss-Jordan over the row: lane of variable v holds row v of the matrix in m[0..11]
+#define QRW_GJ16(C) "v_fmac_f64_dpp %" #C ", %" #C ", %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+template <int P>
+__device__ __forceinline__ void gj16_pivot(double (&m)[12], int v) {
+  double piv = 0.0;
+  const double one = 1.0;
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(piv) : "v"(m[P]), "v"(one), "n"(QRW_VL(P)));
+  const double d = fast_rcp(piv);
+  const double f = (v == P) ? (d - 1.0) : (-m[P] * d);
+  asm("s_nop 1\n\t" QRW_GJ16(0) QRW_GJ16(1) QRW_GJ16(2) QRW_GJ16(3) QRW_GJ16(4) QRW_GJ16(5) QRW_GJ16(6) QRW_GJ16(7) QRW_GJ16(8)
+      QRW_GJ16(9) QRW_GJ16(10) QRW_GJ16(11)
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]),
+        "+v"(m[10]), "+v"(m[11])
+      : "v"(f), "n"(QRW_VL(P)));
+  m[P] = (v == P) ? d : f;
+}
+#undef QRW_GJ16
+__device__ __forceinline__ void gj16_invert(double (&m)[12], int v) {
+  gj16_pivot<0>(m, v); gj16_pivot<1>(m, v); gj16_pivot<2>(m, v); gj16_pivot<3>(m, v); gj16_pivot<4>(m, v); gj16_pivot<5>(m, v);
+  gj16_pivot<6>(m, v); gj16_pivot<7>(m, v); gj16_pivot<8>(m, v); gj16_pivot<9>(m, v); gj16_pivot<10>(m, v); gj16_pivot<11>(m, v);
+}
+// the x, y, z values of this lane's foot (from lanes 0, 1, 2 of its quad)
+__device__ __forceinline__ void foot_xyz(double v, double (&o)[3]) { o[0] = quad_bcast<0>(v); o[1] = quad_bcast<1>(v); o[2] = quad_bcast<2>(v); }
+// the five cone-row values of this lane's foot: slot A of lanes 0..3, slot B of lane 3
+__device__ __forceinline__ void foot_rows(double vA, double vB, double (&o)[5]) {
+  o[0] = quad_bcast<0>(vA); o[1] = quad_bcast<1>(vA); o[2] = quad_bcast<2>(vA); o[3] = quad_bcast<3>(vA); o[4] = quad_bcast<3>(vB);
+}
+
+// QP of one instance on one 16-lane row.  H: this lane's row of H; g: its entry of the linear cost; lo / up: bounds of its two row
+// slots.  st: the instance's persistent state.  sol: D x of this lane's variable.
+__device__ void qp_solve16(const double (&H)[12], double g, const double (&lo)[2], const double (&up)[2], double* st, int j, int t,
+                           bool valid, double& sol, int& iter_out, int& status_out) {
+  const double mu = 0.9;
+  const double sigma = 1e-6, alpha = 1.6;
+  const double eps_abs = (double)(float)1e-5, eps_rel = (double)(float)1e-5;  // QPWBC.cpp:239-240
+  const double eps_prim_inf = 1e-4, eps_dual_inf = 1e-4;
+  const bool isvar = t < 3, isB = (t == 3);
+  const int v = isvar ? 3 * j + t : -1;
+  const int vs = isvar ? 3 * j + t : 3 * j;  // (pad lanes read foot j's x entry: never used)
+  WPH(3);
+  const double init_flag = st[kWsInit];
+  double x = st[kWsX + vs], gprev = st[kWsG + vs], rho = st[kWsRho];
+  double z[2] = {st[kWsZ + 5 * j + t], st[kWsZ + 5 * j + 4]}, y[2] = {st[kWsY + 5 * j + t], st[kWsY + 5 * j + 4]};
+  const bool first = !valid || !(init_flag != 0.0);
+  if (first) {
+    rho = 0.1;
+    x = 0.0; gprev = g;
+    z[0] = z[1] = y[0] = y[1] = 0.0;
+  }
+  if (!isvar) { x = 0.0; gprev = 0.0; }
+  // Gabs of this lane's variable against the five rows of its foot, and of its two row slots against x, y, z (QPWBC.cpp:10-22)
+  const double gv[5] = {(t == 0) ? 1.0 : (t == 2) ? mu : 0.0, (t == 0) ? 1.0 : (t == 2) ? mu : 0.0, (t == 1) ? 1.0 : (t == 2) ? mu : 0.0,
+                        (t == 1) ? 1.0 : (t == 2) ? mu : 0.0, (t == 2) ? 1.0 : 0.0};
+  const double gA[3] = {(t < 2) ? 1.0 : 0.0, (t >= 2) ? 1.0 : 0.0, mu};  // slot A: row t
+  // ---- scale_data (ten passes), wbc_kernel's expressions
+  // The inf-norm of this lane's row of c D H D is (c D_v) * max_cb(|H[cb]| D_cb): hm = that maximum is taken ONCE per pass, after
+  // the update of D -- the pass's cost normalisation and the next pass's column norm both read it (wbc_kernel evaluates the twelve
+  // triple products twice per pass; same values up to the rounding of the last product, a preconditioner like the rsqrt below)
+  double D = 1.0, E[2] = {1.0, 1.0}, cs = 1.0;
+  double Habs[12], hm = 0.0;
+#pragma unroll
+  for (int cb = 0; cb < 12; cb++) { Habs[cb] = fabs(H[cb]); hm = fmax(hm, Habs[cb]); }
+  for (int pass = 0; pass < 10; pass++) {
+    double Ef[5], Df[3];
+    foot_rows(E[0], E[1], Ef);
+    foot_xyz(D, Df);
+    double nD = (cs * D) * hm;
+#pragma unroll
+    for (int c = 0; c < 5; c++) nD = fmax(nD, Ef[c] * gv[c] * D);
+    double nE[2] = {0.0, 0.0};
+#pragma unroll
+    for (int tt = 0; tt < 3; tt++) nE[0] = fmax(nE[0], E[0] * gA[tt] * Df[tt]);
+    nE[1] = fmax(nE[1], E[1] * 1.0 * Df[2]);  // row 4: (0, 0, 1)
+    D *= rsqrt(limit_scaling(nD));
+    E[0] *= rsqrt(limit_scaling(nE[0]));
+    E[1] *= rsqrt(limit_scaling(nE[1]));
+    {
+      double Dall[12];
+      Dall[0] = row_bcast<QRW_VL(0)>(D); Dall[1] = row_bcast<QRW_VL(1)>(D); Dall[2] = row_bcast<QRW_VL(2)>(D);
+      Dall[3] = row_bcast<QRW_VL(3)>(D); Dall[4] = row_bcast<QRW_VL(4)>(D); Dall[5] = row_bcast<QRW_VL(5)>(D);
+      Dall[6] = row_bcast<QRW_VL(6)>(D); Dall[7] = row_bcast<QRW_VL(7)>(D); Dall[8] = row_bcast<QRW_VL(8)>(D);
+      Dall[9] = row_bcast<QRW_VL(9)>(D); Dall[10] = row_bcast<QRW_VL(10)>(D); Dall[11] = row_bcast<QRW_VL(11)>(D);
+      hm = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) hm = fmax(hm, Habs[cb] * Dall[cb]);
+    }
+    const double vcol = (cs * D) * hm;
+    double vf3[3];
+    foot_xyz(vcol, vf3);
+    const double colsum = (vf3[0] + vf3[1]) + vf3[2];  // the foot's three columns, summed as wbc_kernel's lane does
+    double qn = isvar ? fabs(cs * D * gprev) : 0.0;
+    double ct = feet_sum(colsum) * (1.0 / 12.0);
+    qn = limit_scaling(row_max(qn));
+    ct = fmax(ct, qn);
+    ct = limit_scaling(ct);
+    cs *= 1.0 / ct;
+  }
+  WPH(4);
+  const double cinv = 1.0 / cs;
+  const double iD = 1.0 / D;
+  const double iE[2] = {1.0 / E[0], 1.0 / E[1]};
+  const double ls[2] = {E[0] * lo[0], E[1] * lo[1]}, us[2] = {E[0] * up[0], E[1] * up[1]};
+  rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+
+  double Ki[12];
+  bool need_factor = true;
+  int iter, status = kStatusUnsolved;
+  double last_np = 0.0, last_nd = 0.0, pri_res = 0.0, dua_res = 0.0;
+  const int max_iter = 4000;
+  for (iter = 1; valid && iter <= max_iter; iter++) {
+    if (need_factor) {  // Khat = c H + sigma D^-2 + rho G' E^2 G; this lane's row; inverse by Gauss-Jordan across the row
+      need_factor = false;
+      double Ef[5], om[5];
+      foot_rows(E[0], E[1], Ef);
+#pragma unroll
+      for (int c = 0; c < 5; c++) om[c] = rho * Ef[c] * Ef[c];
+      const double s4 = om[0] + om[1] + om[2] + om[3];
+      const double cone[3][3] = {{om[0] + om[1], 0.0, mu * (om[1] - om[0])},
+                                 {0.0, om[2] + om[3], mu * (om[3] - om[2])},
+                                 {mu * (om[1] - om[0]), mu * (om[3] - om[2]), mu * mu * s4 + om[4]}};
+      const int tc = isvar ? t : 0;
+      double crow[3];  // this lane's row of its foot's 3 x 3 block, sigma / D^2 on the diagonal
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        crow[e] = (tc == 0) ? cone[0][e] : (tc == 1) ? cone[1][e] : cone[2][e];
+        if (e == tc) crow[e] += sigma * iD * iD;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 12; cb++) {
+        const double kv = cs * H[cb] + ((cb / 3 == j) ? crow[cb % 3] : 0.0);
+        Ki[cb] = isvar ? kv : 0.0;  // (pad lanes: a zero row, which the elimination leaves zero)
+      }
+      gj16_invert(Ki, v);
+    }
+    const double rho_inv = 1.0 / rho;
+    // rhs (hatted): sigma x / D - c g + G' E (rho z - y)
+    const double wA = E[0] * (rho * (z[0] - rho_inv * y[0])), wB = E[1] * (rho * (z[1] - rho_inv * y[1]));
+    double w[5], gt3[3];
+    foot_rows(wA, wB, w);
+    cone_rows_t(w, mu, gt3);
+    const double gt = (t == 0) ? gt3[0] : (t == 1) ? gt3[1] : gt3[2];
+    const double r = isvar ? sigma * x * iD - cs * g + gt : 0.0;
+    const double xh = row_matvec12(0.0, r, Ki);
+    double xh3[3], cv5[5];
+    foot_xyz(xh, xh3);
+    cone_rows(xh3, mu, cv5);
+    const double cvA = (t == 0) ? cv5[0] : (t == 1) ? cv5[1] : (t == 2) ? cv5[2] : cv5[3];
+    const double zt[2] = {E[0] * cvA, E[1] * cv5[4]};
+    const double xn = alpha * (xh * iD) + (1.0 - alpha) * x;
+    const double dx = xn - x;
+    x = xn;
+    double dy[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; s_++) {
+      const double zr = alpha * zt[s_] + (1.0 - alpha) * z[s_];
+      double zn = zr + rho_inv * y[s_];
+      zn = fmin(fmax(zn, ls[s_]), us[s_]);
+      dy[s_] = rho * (zr - zn);
+      y[s_] += dy[s_];
+      z[s_] = zn;
+    }
+    if (iter % 25 == 0) {
+      const double xs = D * x;
+      double xs3[3];
+      foot_xyz(xs, xs3);
+      cone_rows(xs3, mu, cv5);
+      const double cvsA = (t == 0) ? cv5[0] : (t == 1) ? cv5[1] : (t == 2) ? cv5[2] : cv5[3];
+      const double cvs[2] = {cvsA, cv5[4]};
+      double pres = 0, nz = 0, nax = 0, pres_s = 0, nz_s = 0, nax_s = 0;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; s_++) {
+        if (s_ == 1 && !isB) continue;  // slot B counts on the pad lane only
+        const double axs = E[s_] * cvs[s_], rs = axs - z[s_];
+        pres_s = fmax(pres_s, fabs(rs)); nz_s = fmax(nz_s, fabs(z[s_])); nax_s = fmax(nax_s, fabs(axs));
+        pres = fmax(pres, fabs(iE[s_] * rs)); nz = fmax(nz, fabs(iE[s_] * z[s_])); nax = fmax(nax, fabs(iE[s_] * axs));
+      }
+      double ey5[5], aty3[3];
+      foot_rows(E[0] * y[0], E[1] * y[1], ey5);
+      cone_rows_t(ey5, mu, aty3);
+      const double aty = (t == 0) ? aty3[0] : (t == 1) ? aty3[1] : aty3[2];
+      double dres = 0, naty = 0, npx = 0, nq = 0, dres_s = 0, naty_s = 0, npx_s = 0, nq_s = 0;
+      {
+        double px = row_matvec12(0.0, xs, H);
+        px *= cs;
+        const double qh = cs * g;
+        if (isvar) {
+          dres = fabs(px + qh + aty); naty = fabs(aty); npx = fabs(px); nq = fabs(qh);
+          dres_s = fabs(D * (px + qh + aty)); naty_s = fabs(D * aty); npx_s = fabs(D * px); nq_s = fabs(D * qh);
+        }
+      }
+      pres = row_max(pres); nz = row_max(nz); nax = row_max(nax);
+      dres = row_max(dres); naty = row_max(naty); npx = row_max(npx); nq = row_max(nq);
+      pri_res = pres;
+      dua_res = cinv * dres;
+      last_np = fmax(nz, nax);
+      last_nd = cinv * fmax(fmax(naty, npx), nq);
+      bool done = false;
+      if (pri_res > kOsqpInfty || dua_res > kOsqpInfty) {
+        status = kStatusNonCvx;
+        done = true;
+      } else {
+        const bool pok = pri_res < eps_abs + eps_rel * last_np;
+        const bool dok = dua_res < eps_abs + eps_rel * last_nd;
+        bool pinf = false, dinf = false;
+        if (!pok) {  // is_primal_infeasible (all bounds finite)
+          double ndy = 0.0, lhs = 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < 2; s_++) {
+            if (s_ == 1 && !isB) continue;
+            ndy = fmax(ndy, fabs(E[s_] * dy[s_]));
+            lhs += us[s_] * fmax(dy[s_], 0.0) + ls[s_] * fmin(dy[s_], 0.0);
+          }
+          ndy = row_max(ndy);
+          lhs = feet_sum(quad_sum(lhs));
+          if (ndy > eps_prim_inf && lhs < -eps_prim_inf * ndy) {
+            double edy5[5], at3[3];
+            foot_rows(E[0] * dy[0], E[1] * dy[1], edy5);
+            cone_rows_t(edy5, mu, at3);
+            double na = isvar ? fabs((t == 0) ? at3[0] : (t == 1) ? at3[1] : at3[2]) : 0.0;
+            na = row_max(na);
+            pinf = na < eps_prim_inf * ndy;
+          }
+        }
+        if (!dok) {  // is_dual_infeasible
+          double ndx = isvar ? fabs(D * dx) : 0.0, qdx = isvar ? (cs * D * g) * dx : 0.0;
+          ndx = row_max(ndx);
+          qdx = feet_sum(quad_sum(qdx));
+          if (ndx > eps_dual_inf && qdx < -cs * eps_dual_inf * ndx) {
+            const double dxs = isvar ? D * dx : 0.0;
+            double npd = fabs(cs * row_matvec12(0.0, dxs, H));
+            npd = row_max(isvar ? npd : 0.0);
+            if (npd < cs * eps_dual_inf * ndx) {
+              double dxs3[3], adx[5];
+              foot_xyz(dxs, dxs3);
+              cone_rows(dxs3, mu, adx);  // Einv A_s dx = G (D dx)
+              bool ok = true;
+#pragma unroll
+              for (int c = 0; c < 5; c++)
+                if (adx[c] > eps_dual_inf * ndx || adx[c] < -eps_dual_inf * ndx) ok = false;
+              dinf = (row_max(ok ? 0.0 : 1.0) == 0.0);
+            }
+          }
+        }
+        if (pok && dok) { status = kStatusSolved; done = true; }
+        else if (pinf) { status = kStatusPrimalInf; done = true; }
+        else if (dinf) { status = kStatusDualInf; done = true; }
+      }
+      if (done) break;
+      if (iter % 200 == 0) {
+        pres_s = row_max(pres_s); nz_s = row_max(nz_s); nax_s = row_max(nax_s);
+        dres_s = row_max(dres_s); naty_s = row_max(naty_s); npx_s = row_max(npx_s); nq_s = row_max(nq_s);
+        const double pn = pres_s / (fmax(nz_s, nax_s) + 1e-10);
+        const double dn = dres_s / (fmax(fmax(naty_s, npx_s), nq_s) + 1e-10);
+        double rho_new = rho * sqrt(pn / (dn + 1e-10));
+        rho_new = fmin(fmax(rho_new, kRhoMin), kRhoMax);
+        if (rho_new > rho * 5.0 || rho_new < rho / 5.0) {
+          rho = rho_new;
+          need_factor = true;
+        }
+      }
+    }
+  }
+  WPH(5);
+#ifdef QRW_PROFILE_WBC
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_wbc_ph[blockIdx.x * 16 + 8] = (unsigned long long)iter;
+#endif
+  if (iter > max_iter) iter = max_iter;
+  if (status == kStatusUnsolved) {
+    const bool pok = pri_res < 10 * eps_abs + 10 * eps_rel * last_np;
+    const bool dok = dua_res < 10 * eps_abs + 10 * eps_rel * last_nd;
+    status = (pok && dok) ? kStatusSolvedInaccurate : kStatusMaxIter;
+  }
+  const bool has_sol = (status == kStatusSolved || status == kStatusSolvedInaccurate || status == kStatusMaxIter);
+  sol = has_sol ? D * x : nan("");
+  if (!has_sol) { x = 0.0; z[0] = z[1] = y[0] = y[1] = 0.0; }
+  if (valid) {
+    if (isvar) { st[kWsX + v] = x; st[kWsG + v] = g; }
+    st[kWsZ + 5 * j + t] = z[0]; st[kWsY + 5 * j + t] = y[0];
+    if (isB) { st[kWsZ + 5 * j + 4] = z[1]; st[kWsY + 5 * j + 4] = y[1]; }
+    if (j == 0 && t == 0) { st[kWsRho] = rho; st[kWsInit] = 1.0; }
+  }
+  iter_out = iter;
+  status_out = status;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64, 1) void wbc16_kernel(WbcArgs a) {
+  const int lane = threadIdx.x;
+  const int r16 = lane & 15;
+  const int j = r16 >> 2, t = r16 & 3;
+  const int tc = (t < 3) ? t : 0;  // component this lane stores (pad lanes store nothing)
+  const bool wr = t < 3;
+  const int b = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = b < a.B;
+  const int bb = valid ? b : 0;
+  WPH(0);
+  const LegC C = leg_consts(j);
+  double* st = a.st + (size_t)bb * kWbcStItems;
+  const double* qv = a.q + (size_t)bb * 19;
+  const double* dqv = a.dq + (size_t)bb * 18;
+  double q[3], dq[3], fc[3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) { q[e] = qv[7 + 3 * j + e]; dq[e] = dqv[6 + 3 * j + e]; fc[e] = a.f_cmd[bb * 12 + 3 * j + e]; }
+  const double contact = a.contacts[bb * 4 + j];
+  const bool stance = (contact != 0.0);
+  {  // k_since_contact (QP_WBC.py:65-66)
+    double ks = st[kWsKsc + j];
+    ks += contact;
+    ks *= contact;
+    if (valid && t == 0) st[kWsKsc + j] = ks;
+  }
+  WPH(1);
+  const LegKin K = leg_kinematics(C, q);
+  const V3 vf = dq[0] * K.J0 + dq[1] * K.J1 + dq[2] * K.J2;
+  V3 acl;
+  {
+    const V3 w0 = dq[0] * K.a0, w1 = w0 + dq[1] * K.a1;
+    const V3 da1 = dq[0] * cross(K.a0, K.a1);
+    const V3 vp1 = cross(w0, K.p1 - K.p0), vp2 = vp1 + cross(w1, K.p2 - K.p1);
+    acl = dq[0] * cross(K.a0, vf) + dq[1] * (cross(da1, K.pf - K.p1) + cross(K.a1, vf - vp1)) +
+          dq[2] * (cross(da1, K.pf - K.p2) + cross(K.a1, vf - vp2));
+  }
+  const V3 goal = mk(a.pgoals[bb * 12 + 0 * 4 + j], a.pgoals[bb * 12 + 1 * 4 + j], a.pgoals[bb * 12 + 2 * 4 + j]);
+  const V3 vgoal = mk(a.vgoals[bb * 12 + 0 * 4 + j], a.vgoals[bb * 12 + 1 * 4 + j], a.vgoals[bb * 12 + 2 * 4 + j]);
+  const V3 agoal = mk(a.agoals[bb * 12 + 0 * 4 + j], a.agoals[bb * 12 + 1 * 4 + j], a.agoals[bb * 12 + 2 * 4 + j]);
+  M3 iJ;
+  inv3x3(K.J0, K.J1, K.J2, iJ);
+  const V3 perr = goal - K.pf;
+  V3 afeet = 100.0 * perr - (2.0 * sqrt(100.0)) * (vf - vgoal) + agoal;
+  if (stance) afeet = 0.0 * afeet;
+  afeet = afeet - acl;
+  const V3 ddq3 = mul(iJ, afeet), dqc3 = mul(iJ, vgoal), qs3 = mul(iJ, perr);
+  const double ddq[3] = {ddq3.x, ddq3.y, ddq3.z};
+  M3 Rb;
+  {
+    const double x = qv[3], y = qv[4], z = qv[5], w = qv[6];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                 tyz = tz * y, tzz = tz * z;
+    Rb.r0 = mk(1 - (tyy + tzz), txy - twz, txz + twy);
+    Rb.r1 = mk(txy + twz, 1 - (txx + tzz), tyz - twx);
+    Rb.r2 = mk(txz - twy, tyz + twx, 1 - (txx + tyy));
+  }
+  const V3 vb = mk(dqv[0], dqv[1], dqv[2]), wb = mk(dqv[3], dqv[4], dqv[5]);
+  const V3 grav = mulT(Rb, mk(0.0, 0.0, QRW_SOLO12_MODEL.gravity));
+  const V3 ab0 = grav + cross(wb, vb);
+  const qrw_link_inertial& BL = QRW_SOLO12_MODEL.base;
+  const double Ib[6] = {BL.inertia[0], BL.inertia[1], BL.inertia[2], BL.inertia[3], BL.inertia[4], BL.inertia[5]};
+  const V3 cb = mk(BL.com[0], BL.com[1], BL.com[2]);
+  M3 Id;
+  Id.r0 = mk(1, 0, 0); Id.r1 = mk(0, 1, 0); Id.r2 = mk(0, 0, 1);
+  V3 Fl, Ml;
+  double tau1[3];
+  leg_newton_euler(C, K, dq, ddq, wb, mk(0, 0, 0), ab0, Fl, Ml, tau1);
+  const V3 Fb = BL.mass * (ab0 + cross(wb, cross(wb, cb)));
+  const V3 Mb = inertia_apply(Ib, Id, mk(0, 0, 0)) + cross(wb, inertia_apply(Ib, Id, wb)) + cross(cb, Fb);
+  const V3 F6 = feet_sum3(Fl) + Fb, M6 = feet_sum3(Ml) + Mb;
+  const double rnea6[6] = {F6.x, F6.y, F6.z, M6.x, M6.y, M6.z};
+  double Aj[6][3], gamma[6];
+  {
+    const V3 r = K.pf;
+    const V3 rt[3] = {Rb.r0, Rb.r1, Rb.r2};
+    double X[6][3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const V3 col = mk(rt[e].x, rt[e].y, rt[e].z);
+      const V3 sc = cross(r, col);
+      X[0][e] = col.x; X[1][e] = col.y; X[2][e] = col.z;
+      X[3][e] = sc.x; X[4][e] = sc.y; X[5][e] = sc.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        const double xv = stance ? X[i][e] : 0.0;
+        Aj[i][e] = (1.0 / a.Y[i]) * xv;
+        s_ += xv * fc[e];
+      }
+      const double xf = feet_sum(s_);
+      gamma[i] = (1.0 / a.Y[i]) * (xf - rnea6[i]);
+    }
+  }
+  const double qd_leg = q[tc] + ((tc == 0) ? qs3.x : (tc == 1) ? qs3.y : qs3.z);   // this lane's component of the leg's q_des / v_des
+  const double vd_leg = (tc == 0) ? dqc3.x : (tc == 1) ? dqc3.y : dqc3.z;
+  if (valid) {
+    if (a.qdes) {
+      double* o = a.qdes + bb * 19;
+      if (r16 < 7) o[r16] = 0.0;  // q_cmd[:7] is never written (solo12InvKin.py:67)
+      if (wr) o[7 + 3 * j + t] = qd_leg;
+    }
+    if (a.vdes) {
+      double* o = a.vdes + bb * 18;
+      if (r16 < 6) o[r16] = 0.0;
+      if (wr) o[6 + 3 * j + t] = vd_leg;
+    }
+    if (a.feet && wr) {  // feet_pos, feet_err, feet_vel as 3x4 each (QP_WBC.py:73-80): this lane's component
+      double* o = a.feet + (size_t)bb * 36;
+      o[t * 4 + j] = (t == 0) ? K.pf.x : (t == 1) ? K.pf.y : K.pf.z;
+      o[12 + t * 4 + j] = (t == 0) ? perr.x : (t == 1) ? perr.y : perr.z;
+      o[24 + t * 4 + j] = (t == 0) ? vf.x : (t == 1) ? vf.y : vf.z;
+    }
+  }
+  WPH(2);
+  // ---- QP data of this lane: its row of H = 0.1 A'A + 5 I (compute_matrices / update_PQ), its g, the bounds of its row slots
+  double H[12], g, lo[2], up[2];
+  {
+    double coef[6], col0[6], col1[6], col2[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      coef[i] = ((tc == 0) ? Aj[i][0] : (tc == 1) ? Aj[i][1] : Aj[i][2]) * 0.1;
+      col0[i] = Aj[i][0]; col1[i] = Aj[i][1]; col2[i] = Aj[i][2];
+    }
+    H[0] = h_entry<0>(col0, coef); H[1] = h_entry<0>(col1, coef); H[2] = h_entry<0>(col2, coef);
+    H[3] = h_entry<1>(col0, coef); H[4] = h_entry<1>(col1, coef); H[5] = h_entry<1>(col2, coef);
+    H[6] = h_entry<2>(col0, coef); H[7] = h_entry<2>(col1, coef); H[8] = h_entry<2>(col2, coef);
+    H[9] = h_entry<3>(col0, coef); H[10] = h_entry<3>(col1, coef); H[11] = h_entry<3>(col2, coef);
+#pragma unroll
+    for (int cbi = 0; cbi < 12; cbi++)
+      if (cbi / 3 == j && cbi % 3 == tc) H[cbi] += 5.0;
+    double gv_ = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gv_ += coef[i] * gamma[i];
+    g = gv_;
+    double gf[5];
+    cone_rows(fc, 0.9, gf);
+    const double gA = (t == 0) ? gf[0] : (t == 1) ? gf[1] : (t == 2) ? gf[2] : gf[3];
+    lo[0] = -gA; up[0] = -gA + 25.0;
+    lo[1] = -gf[4]; up[1] = -gf[4] + 25.0;
+  }
+  double sol;
+  int it, stt;
+  qp_solve16(H, g, lo, up, st, j, t, valid, sol, it, stt);
+  WPH(6);
+  // ---- epilogue: ddq_res = A f_res + gamma, second Newton-Euler with the base acceleration, torques, (fused) result check
+  double sol3[3];
+  foot_xyz(sol, sol3);
+  const double fw[3] = {sol3[0] + fc[0], sol3[1] + fc[1], sol3[2] + fc[2]};
+  double dd[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) acc = (e == 0) ? Aj[i][0] * sol3[0] : acc + Aj[i][e] * sol3[e];
+    dd[i] = feet_sum(acc) + gamma[i];
+  }
+  double tau2[3], tff3[3];
+  {
+    const V3 alb = mk(dd[3], dd[4], dd[5]);
+    const V3 ab1 = ab0 + mk(dd[0], dd[1], dd[2]);
+    leg_newton_euler(C, K, dq, ddq, wb, alb, ab1, Fl, Ml, tau2);
+    const V3 fbv = mulT(Rb, mk(fw[0], fw[1], fw[2]));  // Rb' f
+    tff3[0] = tau2[0] - (stance ? dot(K.J0, fbv) : 0.0);
+    tff3[1] = tau2[1] - (stance ? dot(K.J1, fbv) : 0.0);
+    tff3[2] = tau2[2] - (stance ? dot(K.J2, fbv) : 0.0);
+  }
+  const double tff = (tc == 0) ? tff3[0] : (tc == 1) ? tff3[1] : tff3[2];
+  if (valid) {
+    if (a.tau_ff && wr) a.tau_ff[bb * 12 + 3 * j + t] = tff;
+    if (a.f_with_delta && wr) a.f_with_delta[bb * 12 + 3 * j + t] = (t == 0) ? fw[0] : (t == 1) ? fw[1] : fw[2];
+    if (a.ddq_res && r16 < 6) {
+      const double dv = (r16 == 0) ? dd[0] : (r16 == 1) ? dd[1] : (r16 == 2) ? dd[2] : (r16 == 3) ? dd[3] : (r16 == 4) ? dd[4] : dd[5];
+      a.ddq_res[bb * 6 + r16] = dv;
+    }
+    if (r16 == 0) { a.iters[bb] = it; a.status[bb] = stt; }
+    if (a.c_cs) {
+      // fused tail of the control iteration: Controller result + security_check (scripts/Controller.py:306-310,341-365; as
+      // glue::result), one joint per lane, flags combined over the row
+      double* cs = a.c_cs + bb;
+      const size_t cB = (size_t)a.B;
+      int err = (int)a.c_cs[bb + (size_t)glue::cERR * cB];
+      const double c_qf = a.c_qfilt[bb * 19 + 7 + 3 * j + tc], c_vs = a.c_vsecu[bb * 12 + 3 * j + tc];
+      const double qsec = (tc == 0) ? M_PI * 0.4 : (tc == 1) ? M_PI * 80 / 180 : M_PI;
+      double e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
+      if (wr) {
+        if (fabs(c_qf) > qsec) e1 = 1.0;
+        if (fabs(c_vs) > 50) e2 = 1.0;
+        if (fabs(tff) > 8) e3 = 1.0;
+        // not in the reference (its comparisons are blind to NaN): a non-finite command stops the robot, code 4 (glue::result)
+        if (!(fabs(tff) <= 1.7976931348623157e308) || !(fabs(qd_leg) <= 1.7976931348623157e308) ||
+            !(fabs(vd_leg) <= 1.7976931348623157e308)) e4 = 1.0;
+      }
+      e1 = row_max(e1); e2 = row_max(e2); e3 = row_max(e3); e4 = row_max(e4);
+      if (err == 0) {  // the WBC counts this iteration: keep its references for the next one
+        if (wr) {
+          cs[(size_t)(glue::cQDES + 3 * j + t) * cB] = qd_leg;
+          cs[(size_t)(glue::cVDES + 3 * j + t) * cB] = vd_leg;
+        }
+        if (e4 != 0.0) err = 4;
+        if (e1 != 0.0) err = 1;
+        if (e2 != 0.0) err = 2;
+        if (e3 != 0.0) err = 3;
+        if (r16 == 0) cs[(size_t)glue::cERR * cB] = (double)err;
+      }
+      if (wr) {
+        double* r = a.c_result + (size_t)bb * 60;  // P | D | q_des | v_des | tau_ff
+        const int i = 3 * j + t;
+        if (err == 0) {
+          r[i] = 3.0; r[12 + i] = 0.2; r[24 + i] = qd_leg; r[36 + i] = vd_leg; r[48 + i] = 0.8 * tff;
+        } else {
+          r[i] = 0.0; r[12 + i] = 0.1; r[24 + i] = 0.0; r[36 + i] = 0.0; r[48 + i] = 0.0;
+        }
+      }
+      if (r16 == 0 && a.c_err) a.c_err[bb] = err;
+    }
+  }
+  WPH(7);
+}
+
 // pseudoInverse<> of the reference (include/qrw/InvKin.hpp:60-66: JacobiSVD, V diag(1/s_i if s_i > eps max(r,c) s_0 else 0) U^H)
 // for the 6 x 6 block M[:6,:6] of the stand-alone QPWBC::run (src/QPWBC.cpp:486-493), any matrix: one-sided (Hestenes) Jacobi
 // SVD, one thread per instance -- rotate pairs of columns of A = Y (and of V) until all columns are orthogonal; then s_i = |a_i|,
@@ -1090,8 +1687,14 @@ int pinv6_launch(const double* d_M18, double* d_Yinv, int B, hipStream_t stream)
 }
 
 int wbc_launch(const WbcArgs& a, hipStream_t stream) {
-  const int blocks = (a.B + 15) / 16;
-  hipLaunchKernelGGL(wbc_kernel, dim3(blocks), dim3(64), 0, stream, a);
+  // full compute: sixteen lanes per instance (wbc16_kernel) unless QRW_WBC16=0 (read per call: the A/B scripts flip it between two
+  // handles of one process); the stand-alone modes 1-3 stay on the quad kernel
+  const char* e16 = getenv("QRW_WBC16");
+  if (a.mode == 0 && !(e16 && e16[0] == '0')) {
+    hipLaunchKernelGGL(wbc16_kernel, dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(wbc_kernel, dim3((a.B + 15) / 16), dim3(64), 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

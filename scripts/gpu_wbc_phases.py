@@ -26,7 +26,7 @@ for it in range(38):
     qf[:, 7:].copy_(r.q_des); vf[:, 6:].copy_(r.v_des)
     if it in (5, 21, 37):
         torch.cuda.synchronize()
-        nb = B // 16
+        nb = B // 16 if os.environ.get("QRW_WBC16", "1") == "0" else B // 4  # wbc_kernel: 16 instances per workgroup, wbc16_kernel: 4
         buf = (C.c_ulonglong * (16 * nb))()
         assert lib.qrw_wbc_get_phase_cycles(buf, nb) == 0
         a = np.array(buf, dtype=np.float64).reshape(nb, 16)
