@@ -154,6 +154,12 @@ int qrw_wbc_compute_host(qrw_handle h, const double *h_q, const double *h_dq, co
                          const double *h_agoals, double *h_tau_ff, double *h_qdes, double *h_vdes,
                          double *h_f_with_delta, double *h_ddq_res, double *h_feet);
 int qrw_wbc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double *h_rho, double *h_k_since_contact);
+/* Scheduling only (no reference counterpart; results agree to rounding, ADMM iteration counts are identical): lanes per robot
+ * instance of qrw_wbc_compute / qrw_wbc_compute_result.  16 (default): one 16-lane DPP row per instance, batch / 4 wavefronts --
+ * 27.9 us per 4096 robots on the whole chip; 4: one quad per instance, batch / 16 wavefronts of 1.55 x the length -- 43.2 us on
+ * the whole chip, but the faster one on a stream restricted to few compute units (the asynchronous control loop's 32).
+ * QRW_WBC16=0 makes 4 the default of new handles. */
+int qrw_wbc_set_lanes(qrw_handle h, int32_t lanes);
 
 /* Stand-alone pieces of the WBC step with the reference's own signatures, for callers that
  * use the bound classes directly (scripts/solo12InvKin.py:62-67, scripts/QP_WBC.py:107-111):

@@ -87,6 +87,11 @@ class Controller_batch:
             loop_cus = max(1, min(int(loop_cus), n_cu - 1))
             self._s_loop = qrw_hip.CuStream(device, 0, loop_cus)
             self._s_mpc = qrw_hip.CuStream(device, loop_cus, n_cu - loop_cus)
+            if 4 * loop_cus < self.B // 4:
+                # the loop's stream owns too few SIMDs for one wavefront per four robots in a single round: the quad WBC kernel
+                # (a quarter of the wavefronts, 1.55 x the length) is the faster one there (measured at batch 4096 on 32 compute
+                # units: 0.21 against 0.31 ms median paced latency)
+                self._b.wbc_set_lanes(4)
             Ng = int(N_gait)
             mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.dev)
             self._snap = [(mk(self.B, 12, self.n_steps + 1), mk(self.B, Ng, 12)) for _ in range(3)]

@@ -64,6 +64,7 @@ struct qrw_handle_s {
   // WBC
   double* wbc_st = nullptr;
   int *wbc_iters = nullptr, *wbc_status = nullptr;
+  int wbc_lanes16 = 1;  // full WBC compute with sixteen lanes per instance (wbc16_kernel); qrw_wbc_set_lanes / QRW_WBC16=0: one quad
   double Y[6];
   // controller glue
   double* ctrl_st = nullptr;
@@ -353,6 +354,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   ALLOC(h->stage_i, B * sizeof(int32_t));
 #undef ALLOC
   base_inertia_diag(h->Y);
+  if (const char* e16 = getenv("QRW_WBC16")) h->wbc_lanes16 = (e16[0] != '0');
   HIP_OK(hipDeviceSynchronize(), "qrw_create sync");
   *out = h;
   return 0;
@@ -668,6 +670,13 @@ static void wbc_common(qrw_handle h, qrw::WbcArgs& a) {
   a.iters = h->wbc_iters;
   a.status = h->wbc_status;
   for (int i = 0; i < 6; i++) a.Y[i] = h->Y[i];
+  a.lanes16 = h->wbc_lanes16;
+}
+
+extern "C" int qrw_wbc_set_lanes(qrw_handle h, int32_t lanes) {
+  if (!h || (lanes != 4 && lanes != 16)) return fail(-1, "qrw_wbc_set_lanes: lanes must be 4 or 16");
+  h->wbc_lanes16 = (lanes == 16);
+  return 0;
 }
 
 extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_dq, const double* d_f_cmd,

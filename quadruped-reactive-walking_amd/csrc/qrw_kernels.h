@@ -125,6 +125,7 @@ struct WbcArgs {
   double Y[6];  // diagonal of the neutral-configuration CRBA base block (constant)
   // optional stand-alone modes (host-API pieces): see wbc_kernel.hip
   int mode;
+  int lanes16;  // full compute (mode 0): 1 = wbc16_kernel (sixteen lanes per instance), 0 = wbc_kernel (one quad per instance)
   const double *in0, *in1, *in2, *in3, *in4, *in5, *in6, *in7, *in8;
   double *out0, *out1, *out2, *out3, *out4;
   // optional fused tail of a control iteration (Controller result + security_check, controller_glue.h)

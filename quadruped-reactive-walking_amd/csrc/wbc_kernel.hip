@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64, 1) void wbc_kernel(WbcArgs a) {
 //   Arithmetic: the per-foot phases, the QP data, the equilibration and the ADMM iteration evaluate wbc_kernel's expressions in
 //   wbc_kernel's order; the KKT inverse is eliminated with m[c] += m_P[c] * f instead of Ki - (f m_P[c]) d and a fast reciprocal:
 //   results agree with wbc_kernel to rounding (tests/test_gpu_wbc.py::test_wbc16_matches_the_quad_kernel), with the oracle as
-//   before.  QRW_WBC16=0 selects wbc_kernel for the full compute (the stand-alone modes always use it).
+//   before.  qrw_wbc_set_lanes(h, 4) / QRW_WBC16=0 select wbc_kernel for the full compute (the stand-alone modes always use it).
 namespace {
 
 template <int CTRL, int RM, int BM>
@@ -1687,10 +1687,11 @@ int pinv6_launch(const double* d_M18, double* d_Yinv, int B, hipStream_t stream)
 }
 
 int wbc_launch(const WbcArgs& a, hipStream_t stream) {
-  // full compute: sixteen lanes per instance (wbc16_kernel) unless QRW_WBC16=0 (read per call: the A/B scripts flip it between two
-  // handles of one process); the stand-alone modes 1-3 stay on the quad kernel
-  const char* e16 = getenv("QRW_WBC16");
-  if (a.mode == 0 && !(e16 && e16[0] == '0')) {
+  // full compute: sixteen lanes per instance (wbc16_kernel: B / 4 wavefronts, every SIMD of the chip at batch 4096) or one quad
+  // per instance (wbc_kernel: B / 16 wavefronts of 1.55 x the length -- the better choice on a stream that owns few compute
+  // units, e.g. the control loop's 32 of the asynchronous MPC mode); the handle decides (qrw_wbc_set_lanes, QRW_WBC16).  The
+  // stand-alone modes 1-3 stay on the quad kernel.
+  if (a.mode == 0 && a.lanes16) {
     hipLaunchKernelGGL(wbc16_kernel, dim3((a.B + 3) / 4), dim3(64), 0, stream, a);
   } else {
     hipLaunchKernelGGL(wbc_kernel, dim3((a.B + 15) / 16), dim3(64), 0, stream, a);

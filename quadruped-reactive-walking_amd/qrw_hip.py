@@ -57,6 +57,7 @@ SIGNATURES = {
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
     "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),
     "qrw_wbc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "qrw_wbc_set_lanes": (C.c_int, [_vp, C.c_int32]),
     "qrw_invkin_host": (C.c_int, [_vp] + [_dp] * 12),
     "qrw_qpwbc_host": (C.c_int, [_vp] + [_dp] * 7),
     "qrw_fixed_feet_host": (C.c_int, [_vp] + [_dp] * 7),
@@ -242,6 +243,11 @@ class Batch:
             self._dev(out["ddq_res"], (B, 6)), self._dev(out["feet"], (B, 3, 3, 4)), self._stream()),
             "qrw_wbc_compute")
         return out
+
+    def wbc_set_lanes(self, lanes):
+        """Lanes per robot instance of the full WBC step: 16 (default, whole-chip streams) or 4 (streams that own few compute
+        units); scheduling only, see qrw_wbc_set_lanes."""
+        _check(self._lib.qrw_wbc_set_lanes(self._handle, int(lanes)), "qrw_wbc_set_lanes")
 
     def mpc_solve_sequence(self, xref, fsteps, first_num_iter=0, out=None, iters=None):
         """K consecutive MPC calls of every instance in one launch, ordered per instance only (qrw_mpc_solve_sequence):

@@ -352,7 +352,7 @@ def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
 
 def test_wbc16_matches_the_quad_kernel(synth_mod, monkeypatch):
     """wbc16_kernel (sixteen lanes per instance, the default for the full compute since round 4) against wbc_kernel (one quad per
-    instance, QRW_WBC16=0) on two handles fed the same sequence: same ADMM iteration counts and status on every call, outputs
+    instance, `wbc_set_lanes(4)`) on two handles fed the same sequence: same ADMM iteration counts and status on every call, outputs
     equal to rounding (the per-foot phases, the QP data, the equilibration and the ADMM iteration evaluate the same expressions
     in the same order; only the 12 x 12 KKT inverse is eliminated in another form), persistent state and k_since_contact
     included.  Odd batch (padded rows), all contact sets, random base poses, warm starts across calls."""
@@ -362,6 +362,9 @@ def test_wbc16_matches_the_quad_kernel(synth_mod, monkeypatch):
     sb = synth_mod.SyntheticBatch(B, 16, gaits=("trot", "walk", "static"), seed0=95000)
     rng = np.random.default_rng(12)
     new, old = qrw_hip.Batch(B), qrw_hip.Batch(B)
+    old.wbc_set_lanes(4)
+    with pytest.raises(qrw_hip.QrwError):
+        old.wbc_set_lanes(8)
     worst = 0.0
     for s in range(10):
         d = sb.step(s)
@@ -372,10 +375,8 @@ def test_wbc16_matches_the_quad_kernel(synth_mod, monkeypatch):
         contacts = d["contacts"] if s % 3 else np.array([[(((b + 5 * s) % 16) >> i) & 1 for i in range(4)] for b in range(B)], dtype=np.float64)
         f = f_cmd_for(contacts, rng)
         args = (d["q"], d["dq"], f, contacts, d["pgoals"], d["vgoals"], d["agoals"])
-        monkeypatch.setenv("QRW_WBC16", "1")
         o1 = new.wbc_compute_host(*args)
         s1 = new.wbc_stats()
-        monkeypatch.setenv("QRW_WBC16", "0")
         o0 = old.wbc_compute_host(*args)
         s0 = old.wbc_stats()
         assert np.array_equal(s1["iters"], s0["iters"]) and np.array_equal(s1["status"], s0["status"]), s
@@ -386,5 +387,4 @@ def test_wbc16_matches_the_quad_kernel(synth_mod, monkeypatch):
             e = rel_err(o1[key], o0[key])
             worst = max(worst, e)
             assert e < 1e-9, (s, key, e)
-    monkeypatch.delenv("QRW_WBC16")
     print("wbc16 vs quad kernel: worst relative deviation %.2e" % worst)
