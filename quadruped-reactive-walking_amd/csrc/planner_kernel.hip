@@ -158,22 +158,31 @@ __device__ void gait_init(Gm& past, Gm& cur, Gm& des, const PlannerArgs& a) {
   for (int k = 0; k < i; k++) rot_up(des, index);
 }
 
-// Gait::getPhaseDuration (src/Gait.cpp:141-182); also leaves remainingTime_
+// Gait::getPhaseDuration (src/Gait.cpp:141-182); also leaves remainingTime_.  The reference walks the rows one by one (forwards
+// through the current gait and on into the desired one, backwards through the current one and on into the past one); on column
+// masks each walk is "count the consecutive rows whose bit equals `value`" = a count of trailing / leading ones: no loop (round 4:
+// the loops' trip counts differ per lane, a wavefront paid the longest one, ~1 k instructions per call).
+__device__ __forceinline__ int trailing_ones(unsigned long long x) { return (~x == 0ull) ? 64 : (__ffsll((long long)~x) - 1); }
 __device__ double phase_duration(const Gm& past, const Gm& cur, const Gm& des, const PlannerArgs& a, int i, int j, bool value,
                                  double& remain) {
-  double t_phase = 1;
-  int b = i;
-  while (!rz(cur, i + 1) && gbit(cur, i + 1, j) == value) { i++; t_phase++; }
-  if (rz(cur, i + 1)) {
-    int k = 0;
-    while (!rz(des, k) && gbit(des, k, j) == value) { k++; t_phase++; }
-  }
-  remain = t_phase;
-  while (b > 0 && gbit(cur, b - 1, j) == value) { b--; t_phase++; }
-  if (b == 0) {
-    while (!rz(past, b) && gbit(past, b, j) == value) { b++; t_phase++; }
-  }
-  return t_phase * a.dt_mpc;
+  const unsigned long long ccur = (j == 0) ? cur.c[0] : (j == 1) ? cur.c[1] : (j == 2) ? cur.c[2] : cur.c[3];
+  const unsigned long long cdes = (j == 0) ? des.c[0] : (j == 1) ? des.c[1] : (j == 2) ? des.c[2] : des.c[3];
+  const unsigned long long cpast = (j == 0) ? past.c[0] : (j == 1) ? past.c[1] : (j == 2) ? past.c[2] : past.c[3];
+  const unsigned long long vcur = value ? ccur : ~ccur, vdes = value ? cdes : ~cdes, vpast = value ? cpast : ~cpast;
+  const unsigned long long nzc = gm_any(cur);
+  // forwards: rows i + 1, i + 2, ... while the row is not all zero and the foot's entry equals `value` (:147-152)
+  const unsigned long long fwd = (i + 1 < 64) ? ((vcur & nzc) >> (i + 1)) : 0ull;
+  const int run = trailing_ones(fwd);
+  int cnt = 1 + run;
+  const int inext = i + run + 1;
+  if (inext >= 64 || ((nzc >> inext) & 1ull) == 0ull) cnt += trailing_ones(vdes & gm_any(des));  // the walk ran into the zero row: on into the desired gait (:154-162)
+  remain = (double)cnt;  // remainingTime_ (:164)
+  // backwards from the ORIGINAL row: rows i - 1, i - 2, ... while the entry equals `value` (no zero-row test, :167-171)
+  const unsigned long long miss = ~vcur & lowmask(i);  // rows below i whose entry differs
+  const int runb = (miss == 0ull) ? i : (i - 1 - (63 - __clzll((long long)miss)));
+  cnt += runb;
+  if (runb == i) cnt += trailing_ones(vpast & gm_any(past));  // reached row 0: on into the past gait (:173-180)
+  return (double)cnt * a.dt_mpc;
 }
 
 // Gait::updateGait = changeGait + rollGait (src/Gait.cpp:184-260); returns whether the gait matrices were rolled
@@ -758,6 +767,12 @@ __device__ __forceinline__ double quadmax_d(double v) {
   o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));
   return fmax(v, o);
 }
+template <int LANE>
+__device__ __forceinline__ double quad_bcast(double v) {  // lane LANE of each quad to its four lanes (quad_perm)
+  constexpr int kCtrl = LANE * 0x55;
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xF, 0xF, true),
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xF, 0xF, true));
+}
 }  // namespace
 
 __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu, PlannerArgs a, ControllerArgs cw, int with_wbc_inputs) {
@@ -771,6 +786,10 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   s.stride = (size_t)a.B;
   const glue::CS cs = glue::state_of(cu, b);
   const double dtw = cu.dt_wbc;
+#ifdef QRW_PROFILE_PRE
+  long long pp_last = clock64();
+  if (threadIdx.x == 0) atomicAdd(&qrw_pre_prof[0], 1ull);
+#endif
 
   // ================= operands of all three pieces, ahead of the first store =================
   double jv[6], vf6[6], rpy_in[3], vf_mine[3], qf_mine[3];
@@ -819,16 +838,23 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     }
   }
 
+  PP(2);
   // ================= Controller.updateState (scripts/Controller.py:381-426) =================
-  const double c0 = cos(yaw0), s0 = sin(yaw0);
+  // Eight sine / cosine pairs of this block and of the footstep planner's head have arguments that are known here: each lane of
+  // the quad evaluates two of them (its own argument, the same library routine: the same bits) and the quad shares the results --
+  // two evaluations per lane instead of eight (round 4: the state update was 13 k of the kernel's 73 k clocks, nearly all trig)
+  const double yaw = yaw0 + jv[5] * dtw;
+  const double ang_a = (j == 0) ? yaw0 : (j == 1) ? rpy_in[0] / 2. : (j == 2) ? rpy_in[1] / 2. : yaw / 2.;
+  const double ang_b = (j == 0) ? rpy_in[0] : (j == 1) ? rpy_in[1] : (j == 2) ? yaw : a.dt_wbc * jv[5];
+  const double sin_a = sin(ang_a), cos_a = cos(ang_a), sin_b = sin(ang_b), cos_b = cos(ang_b);
+  const double c0 = quad_bcast<0>(cos_a), s0 = quad_bcast<0>(sin_a);
   const double qx = qx0 + (c0 * jv[0] + -s0 * jv[1]) * dtw;
   const double qy = qy0 + (s0 * jv[0] + c0 * jv[1]) * dtw;
-  const double yaw = yaw0 + jv[5] * dtw;
   double q7[7];
   q7[0] = qx; q7[1] = qy; q7[2] = qf2;
   {
-    const double sr = sin(rpy_in[0] / 2.), cr = cos(rpy_in[0] / 2.), sp = sin(rpy_in[1] / 2.), cp = cos(rpy_in[1] / 2.),
-                 sy = sin(yaw / 2.), cy = cos(yaw / 2.);
+    const double sr = quad_bcast<1>(sin_a), cr = quad_bcast<1>(cos_a), sp = quad_bcast<2>(sin_a), cp = quad_bcast<2>(cos_a),
+                 sy = quad_bcast<3>(sin_a), cy = quad_bcast<3>(cos_a);
     q7[3] = sr * cp * cy - cr * sp * sy;
     q7[4] = cr * sp * cy + sr * cp * sy;
     q7[5] = cr * cp * sy - sr * sp * cy;
@@ -836,7 +862,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   }
   double hv[6];
   {
-    const double cr = cos(rpy_in[0]), sr = sin(rpy_in[0]), cp = cos(rpy_in[1]), sp = sin(rpy_in[1]);
+    const double cr = quad_bcast<0>(cos_b), sr = quad_bcast<0>(sin_b), cp = quad_bcast<1>(cos_b), sp = quad_bcast<1>(sin_b);
     const double R[9] = {cp, sp * sr, sp * cr, 0.0, cr, -sr, -sp, cp * sr, cp * cr};
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
       hv[3 + r] = R[r * 3] * vf6[3] + R[r * 3 + 1] * vf6[4] + R[r * 3 + 2] * vf6[5];
     }
   }
-  const double cyw = cos(yaw), syw = sin(yaw);
+  const double cyw = quad_bcast<2>(cos_b), syw = quad_bcast<2>(sin_b);
   {
     double* q = cu.out0 + (size_t)b * 19;
     double* v = cu.out1 + (size_t)b * 18;
@@ -875,6 +901,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   double rpy[3];
   quat_to_rpy(q7 + 3, rpy);
 
+  PP(1);
   // ================= Gait::updateGait (all four lanes hold the whole matrices as bit masks) =================
   if (j == 0) {
     s(L.isstatic) = (code == 4) ? 1.0 : 0.0;
@@ -884,6 +911,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   gait_update(past, cur, des, a, k, code, newphase);
   if (j == 0 && k % a.k_mpc == 0) s(L.newphase) = newphase;
 
+  PP(3);
   // ================= FootstepPlanner::updateFootsteps, this lane's foot =================
   double last_call = -1.0;  // order key of this lane's last getPhaseDuration call (table: 4 i + j, trajectory: 4 N_gait + j)
   const bool ct0 = gbit(cur, 0, j);
@@ -892,8 +920,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     for (int r = 0; r < 3; r++) cf[r] = fs1[r];
   }
   {
-    const double ry = a.dt_wbc * vr[5];
-    const double c = cos(ry), sn = sin(ry);
+    const double c = quad_bcast<3>(cos_b), sn = quad_bcast<3>(sin_b);  // of dt_wbc * v_ref(5), the rotation of the last time step
     const double dpx = a.dt_wbc * vr[0], dpy = a.dt_wbc * vr[1];
     if (ct0) {
       const double x = cf[0] - dpx, y = cf[1] - dpy;
@@ -909,8 +936,101 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
 #pragma unroll
   for (int r = 0; r < 3; r++) row[r] = ct0 ? cf[r] : 0.0;
   const double w = vr[5];
-  double dtc_prev = a.dt_wbc * a.k_footsteps;
   const double cross0 = hv[1] * vr[5] - hv[2] * vr[4], cross1 = hv[2] * vr[3] - hv[0] * vr[5];
+  PP(4);
+  // The table row by row (src/FootstepPlanner.cpp:76-152) is cheap -- a stance foot keeps its row, a swing foot has zeros -- except
+  // at a TOUCH-DOWN (swing -> stance): yaw sine / cosine, the displacement integrals, getPhaseDuration, the Raibert terms.  A
+  // foot touches down once or twice in the table, but at a different row on every lane, so a wavefront that walks the rows
+  // together executes the expensive branch at nearly every row (round 4: 25.7 k of the kernel's 73 k clocks).  Here each lane
+  // first finds ITS touch-down rows with mask arithmetic, the wavefront then computes "the k-th touch-down of every lane" together
+  // (once or twice in all), and the row loop only selects and stores.  Same arithmetic per touch-down, same call order of
+  // getPhaseDuration per foot (remainingTime_, `last_call`).  More than kTdMax touch-downs on some lane: the row-wise form.
+  constexpr int kTdMax = 4;
+  const unsigned long long colj = (j == 0) ? cur.c[0] : (j == 1) ? cur.c[1] : (j == 2) ? cur.c[2] : cur.c[3];
+  const unsigned long long anyrow = gm_any(cur) | 1ull;                 // (row 0 is not tested by the reference's walk)
+  const int zrow = (~anyrow == 0ull) ? 64 : (__ffsll((long long)~anyrow) - 1);  // first all-zero row >= 1: the walk stops there
+  const unsigned long long livem = lowmask(zrow < Ng ? zrow : Ng);
+  unsigned long long tdm = colj & ~(colj << 1) & livem & ~1ull;        // rows i >= 1 with gait(i-1, j) = 0, gait(i, j) = 1
+  const bool rowwise = __any(__popcll(tdm) > kTdMax);
+  double tdv[kTdMax][3];
+#pragma unroll
+  for (int q = 0; q < kTdMax; q++) tdv[q][0] = tdv[q][1] = tdv[q][2] = 0.0;
+  if (!rowwise) {
+    unsigned long long left = tdm;
+    double dtc = a.dt_wbc * a.k_footsteps;  // dt_cum of the row before the touch-down: one addition per row, as the reference
+    int irow = 1;
+#pragma unroll
+    for (int q = 0; q < kTdMax; q++) {
+      if (!__any(left != 0ull)) break;
+      const bool have = left != 0ull;
+      const int i = have ? (__ffsll((long long)left) - 1) : irow;
+      left &= left - 1ull;
+      for (; irow < i; irow++) dtc = dtc + a.dt_mpc;  // (rows 1 .. i - 1 are live: each adds dt)
+      if (have) {
+        const double yawp = w * dtc;
+        const double c = cos(yawp), sn = sin(yawp);
+        double dxp, dyp;
+        if (w != 0) {
+          dxp = (hv[0] * sn + hv[1] * (c - 1.0)) / w;
+          dyp = (hv[1] * sn - hv[0] * (c - 1.0)) / w;
+        } else {
+          dxp = hv[0] * dtc;
+          dyp = hv[1] * dtc;
+        }
+        const double t_stance = phase_duration(past, cur, des, a, i, j, true, remain);
+        last_call = (double)(4 * i + j);
+        double nf[3];
+        const double cr[3] = {cross0, cross1, 0.0};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          double v = t_stance * 0.5 * hv[r];
+          v += a.k_feedback * (hv[r] - vr[r]);
+          v += 0.5 * sqrt(a.h_ref / a.g) * cr[r];
+          nf[r] = v;
+        }
+        nf[0] = fmax(fmin(nf[0], a.L), -a.L);
+        nf[1] = fmax(fmin(nf[1], a.L), -a.L);
+        nf[0] += a.shoulders[0 * 4 + j];
+        nf[1] += a.shoulders[1 * 4 + j];
+        nf[2] = 0.0;
+        tdv[q][0] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
+        tdv[q][1] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
+        tdv[q][2] = (0.0 * nf[0] + 0.0 * nf[1] + 1.0 * nf[2]) + 0.0;
+      }
+    }
+    const unsigned long long stm = colj & livem;            // rows in stance (and live)
+    const unsigned long long carrym = stm & (colj << 1);    // ... that continue a stance
+    // running pointers (one 64-bit add per row instead of a 64-bit multiply-add per store), no branch in the loop body
+    // On an iteration that does not solve (no fsteps output, xref_steps = 1: qrw_control_pre without the MPC's inputs) nobody reads
+    // the table before the next solving iteration rewrites it -- except row 1, which updateNewContact takes at the next gait
+    // change (src/FootstepPlanner.cpp:225-230): rows 0 and 1 of the state copy are kept current, the rest waits (the target
+    // footsteps come from the registers).  54 of 60 stores fewer on nine iterations of ten.
+    const bool full_table = (fo != nullptr) || (a.xref_steps == 0);
+    const size_t row_stride = 12 * s.stride;
+    double* p0 = &s(FSI(0, 0, j));
+    double* p1 = &s(FSI(0, 1, j));
+    double* p2 = &s(FSI(0, 2, j));
+    double* pf = fo ? fo + 3 * j : nullptr;
+    for (int i = 0; i < Ng; i++) {
+      const bool td = i > 0 && ((tdm >> i) & 1ull) != 0ull, keep = i == 0 || ((carrym >> i) & 1ull) != 0ull;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        row[r] = td ? tdv[0][r] : (keep ? row[r] : 0.0);
+        // the touch-down values are consumed in order: shift the next one up (static indices only: register arrays)
+        tdv[0][r] = td ? tdv[1][r] : tdv[0][r];
+        tdv[1][r] = td ? tdv[2][r] : tdv[1][r];
+        tdv[2][r] = td ? tdv[3][r] : tdv[2][r];
+      }
+      if (full_table || i < 2) { *p0 = row[0]; *p1 = row[1]; *p2 = row[2]; }
+      p0 += row_stride; p1 += row_stride; p2 += row_stride;
+      if (pf) { pf[0] = row[0]; pf[1] = row[1]; pf[2] = row[2]; pf += 12; }
+      const bool take = !found && (row[0] != 0.0 || i == Ng - 1);
+      tg[0] = take ? row[0] : tg[0];
+      tg[1] = take ? row[1] : tg[1];
+      found = found || take;
+    }
+  } else {
+  double dtc_prev = a.dt_wbc * a.k_footsteps;
   bool live = true;
   for (int i = 0; i < Ng; i++) {
     if (i > 0) {
@@ -967,6 +1087,8 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
       tg[1] = row[1];
     }
   }
+  }
+  PP(5);
   double otgt[3];
   {
     const double c = cos(rpy[2]), sn = sin(rpy[2]);
@@ -981,6 +1103,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     s(L.otgt + 4 + j) = otgt[1];
   }
 
+  PP(6);
   // ================= FootTrajectoryGenerator::update, this lane's foot =================
   {
     unsigned swing = 0;
@@ -1032,6 +1155,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     if (last_call >= 0.0 && last_call == mx) s(L.remain) = remain;
   }
 
+  PP(7);
   // ================= StatePlanner::computeReferenceStates: the horizon steps dealt to the four lanes =================
   double xr1_6 = 0.0, xr1_7 = 0.0;  // rows 6, 7 of column 1 (the WBC target assembly reads them back)
   if (a.xref) {
@@ -1077,6 +1201,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     }
   }
 
+  PP(8);
   // ================= remaining planner outputs / state =================
   if (a.gait) {
     double* o = a.gait + (size_t)b * Ng * 4;
@@ -1096,6 +1221,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
     s(L.des + j) = __longlong_as_double((long long)dc);
   }
 
+  PP(9);
   // ================= WBC target assembly (scripts/Controller.py:258-296), this lane's foot =================
   if (with_wbc_inputs) {
     const double h_ref = cw.h_ref;
@@ -1149,6 +1275,7 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
       cs(glue::cPCMD + r * 4 + j) = rp[r];
     }
   }
+  PP(10);
 }
 
 #undef FSI

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 import numpy as np, torch
 from Controller import Controller_batch
-B = 4096
+B = int(os.environ.get("QRW_EXP_B", "4096"))
 dev = torch.device("cuda:0")
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
 ctl = Controller_batch(B, q_init, fused=(len(sys.argv) < 2 or sys.argv[1] != 'separate'))
