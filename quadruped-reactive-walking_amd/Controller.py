@@ -7,6 +7,7 @@ HIP kernel of libqrw_hip.so working on the same handle; nothing leaves HBM.  The
 PyBullet / masterboard devices and the loggers are outside the accelerated path: their outputs (reference velocity,
 filtered q / v, roll-pitch, joint velocities for the security check) are inputs here.
 """
+import os
 import numpy as np
 
 import qrw_hip
@@ -87,7 +88,8 @@ class Controller_batch:
             loop_cus = max(1, min(int(loop_cus), n_cu - 1))
             self._s_loop = qrw_hip.CuStream(device, 0, loop_cus)
             self._s_mpc = qrw_hip.CuStream(device, loop_cus, n_cu - loop_cus)
-            if 4 * loop_cus < self.B // 4:
+            lanes_exp = os.environ.get("QRW_EXP_ASYNC_LANES")  # experiments only (scripts/gpu_async_cus_exp.py)
+            if (lanes_exp == "4") if lanes_exp else (4 * loop_cus < self.B // 4):
                 # the loop's stream owns too few SIMDs for one wavefront per four robots in a single round: the quad WBC kernel
                 # (a quarter of the wavefronts, 1.55 x the length) is the faster one there (measured at batch 4096 on 32 compute
                 # units: 0.21 against 0.31 ms median paced latency)
