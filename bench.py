@@ -373,6 +373,9 @@ def main():
                 out["secondary_ratio_1_10_two_groups_staggered"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2, free_running=True,
                                                                                         stagger=True)
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
+            # the same mode with 64 instead of 32 compute units for the loop's stream: one SIMD per wavefront of the loop's kernels at
+            # batch 4096 -- the latency-oriented setting (Controller_batch(loop_cus=64)), paid for in free-running rate
+            out["secondary_ratio_1_10_async_64cu"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True, loop_cus=64)
         if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
             # the metric reads "batch {1, 256, 4096}" and BASELINE lists configs 2 and 4: every single-GPU figure in this ONE line
             out["batch_1"] = config_leg(1, 16, ("trot",), dev, W=3, K=20)
