@@ -124,6 +124,12 @@ int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double 
  * the cold restart of the next qrw_mpc_solve can be checked without provoking a give-up.  -1 on other handles. */
 int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at);
 
+/* Tests only: (poison != 0) fill the LDS of every compute unit with `lds_pattern`, then run the known-answer solve of
+ * mpc_solve_kernel for horizon N in launch form mode (0 one launch per call, 1 time-sliced: N > 16, 2 sequence) without the
+ * per-process cache of qrw_create; 0 = the answer is right.  Catches reads of LDS the kernel has not written. */
+int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t *iters, int32_t *status,
+                          double *rho, double *err);
+
 /* Diagnostic: the block order the NEXT qrw_mpc_solve will use (h_order[i] = instance solved by workgroup i: a
  * permutation of 0..B-1, longest predicted solve first) and the moving average of iteration counts it was sorted by
  * (either may be NULL).  *has_order = 0 while no order exists (batch <= 1024, or before the first solve).  Synchronises
@@ -273,7 +279,10 @@ int qrw_mpc_result_shift(qrw_handle h, const double *d_gait, double *d_x_f_mpc, 
  * qrw_wbc_compute_result = qrw_wbc_compute + qrw_controller_result (scripts/Controller.py:200-326 end to end in two
  * launches plus the MPC solve every k_mpc-th iteration).  Operands as in the separate entry points.  d_fsteps and d_gait may
  * be NULL; with d_fsteps NULL and d_x_f_mpc given (an iteration that does not solve: nobody reads the MPC's inputs) only
- * column 0 and horizon step 1 of d_xref are written, which is all the WBC target assembly reads of it. */
+ * column 0 and horizon step 1 of d_xref are written, which is all the WBC target assembly reads of it, and of the planner's
+ * own copy of the footstep table (qrw_planner_get item "fsteps") only rows 0 and 1 are refreshed -- row 1 is what
+ * updateNewContact may take at the next gait change (src/FootstepPlanner.cpp:225-230), the other rows are rewritten by the
+ * next call with d_fsteps before anything reads them. */
 int qrw_control_pre(qrw_handle h, int32_t k, const double *d_joy_vref, const double *d_q_filt, const double *d_v_filt,
                     const double *d_rpy, const int32_t *d_code, int32_t code_scalar, const double *d_x_f_mpc, double *d_q,
                     double *d_v, double *d_hv, double *d_vref, double *d_oRh_oTh, double *d_xref, double *d_fsteps,

@@ -105,12 +105,17 @@ __device__ __forceinline__ void cone_apply_t(const double w[5], double mu, doubl
 // (Measured and dropped, round 3: leaving out the second barrier where another workgroup barrier separates this exchange from the
 // next one through the buffer anyway -- the force-elimination exchange of the ADMM loop -- is 1.9 % SLOWER at N = 32, A/B on one
 // box: 91.4 k against 93.2 k control steps/s; a second buffer for the other exchange costs the kernel 12-36 B of scratch.)
-template <int NW>
+// CL (one wavefront, runtime horizon N < 16): a step without a successor reads ITSELF, as the LDS form below does.  The caller
+// multiplies what comes back by a 0 coefficient then, but lane + 4 would be a quad of an idle step, whose values derive from LDS
+// nobody has written: 0 x NaN.  (With the compile-time horizon lane + 4 of step 15 wraps to step 0: finite.)  Found by filling the
+// LDS with NaN before the known-answer solve (qrw_test_known_answer; tests/test_gpu_api_errors.py).
+template <int NW, bool CL = false>
 __device__ __forceinline__ void nb_next(const double v[3], double same[3], double shifted[3], double* sE, int k, int j,
                                         int lane, bool has_next) {
   if constexpr (NW == 1) {
+    const int s4 = (CL && !has_next) ? lane : lane + 4, s2 = (CL && !has_next) ? lane : lane + 2;
 #pragma unroll
-    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], lane + 4); shifted[t] = shfl(v[t], lane + 2); }
+    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], s4); shifted[t] = shfl(v[t], s2); }
   } else {
 #pragma unroll
     for (int t = 0; t < 3; t++) sE[k * 12 + 3 * j + t] = v[t];
@@ -122,12 +127,13 @@ __device__ __forceinline__ void nb_next(const double v[3], double same[3], doubl
   }
 }
 // same[t] = value of lane (k-1, j); shifted[t] = value of lane (k-1, j+2) (only meaningful for j < 2).
-template <int NW>
+template <int NW, bool CL = false>
 __device__ __forceinline__ void nb_prev(const double v[3], double same[3], double shifted[3], double* sE, int k, int j,
                                         int lane, bool has_prev) {
   if constexpr (NW == 1) {
+    const int s4 = (CL && !has_prev) ? lane : lane - 4, s2 = (CL && !has_prev) ? lane : lane - 2;
 #pragma unroll
-    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], lane - 4); shifted[t] = shfl(v[t], lane - 2); }
+    for (int t = 0; t < 3; t++) { same[t] = shfl(v[t], s4); shifted[t] = shfl(v[t], s2); }
   } else {
 #pragma unroll
     for (int t = 0; t < 3; t++) sE[k * 12 + 3 * j + t] = v[t];
@@ -659,6 +665,28 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   PH_DECL
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
+#ifdef QRW_DEBUG_POISON
+  // diagnostic build (scripts/gpu_poison_bisect.py): one member of the LDS struct filled with NaN before anything else runs, the
+  // member chosen by the otherwise unused pre_bin -- which unwritten LDS does a solve read?
+  if constexpr (!SEQ && !PRE && !DIS) {
+    const double qnan = __longlong_as_double(-1ll);
+    auto fill = [&](double* p, int n) { for (int e = tid; e < n; e += 64 * NW) p[e] = qnan; };
+    switch (a.pre_bin) {
+      case 1: fill(L.sN, (int)(sizeof(L.sN) / 8)); break;
+      case 2: fill(L.sX, (int)(sizeof(L.sX) / 8)); break;
+      case 3: fill(L.sDump, (int)(sizeof(L.sDump) / 8)); break;
+      case 4: fill(L.sE, (int)(sizeof(L.sE) / 8)); break;
+      case 5: fill(L.sW, (int)(sizeof(L.sW) / 8)); break;
+      case 6: fill(L.sOm, (int)(sizeof(L.sOm) / 8)); break;
+      case 7: fill(L.sDg, (int)(sizeof(L.sDg) / 8)); break;
+      case 8: fill(L.sA, kMatSz); break;
+      case 9: fill(L.sB, kMatSz); break;
+      case 10: fill(L.sRed, 4); fill(L.sPre, 8); break;
+      default: break;
+    }
+    __syncthreads();
+  }
+#endif
   {
   int b, seq_s = 0;
 #ifdef QRW_SEQ_STATS
@@ -930,7 +958,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     double EdL[3], EdA[3], mDf[3], mBD[3];
     double EnV[3], En6V[3], DxpV[3], Dxp6V[3];
     if constexpr (DIS) { nb_next_dis(Ed, EnV, En6V, L.sEb[2], k, j, lane); nb_prev_dis(Dx0, DxpV, Dxp6V, L.sEb[3], k, j, lane); }
-    else { nb_next<NW>(Ed, EnV, En6V, L.sE, k, j, lane, has_next); nb_prev<NW>(Dx0, DxpV, Dxp6V, L.sE, k, j, lane, has_prev); }
+    else { nb_next<NW, !FULL>(Ed, EnV, En6V, L.sE, k, j, lane, has_next); nb_prev<NW, !FULL>(Dx0, DxpV, Dxp6V, L.sE, k, j, lane, has_prev); }
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const double En = EnV[t], En6 = En6V[t], Dxp = DxpV[t], Dxp6 = Dxp6V[t];
@@ -1167,7 +1195,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) { wnV[t] = shfl(wD[t], lane + 4); wn6V[t] = shfl(wD[t], lane + 2); }
       } else {
-        nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
+        nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
       }
     PH(0);
     }  // need_factor
@@ -1217,7 +1245,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) gnV[t] = shfl(gsV[t], lane + 4);
       } else {
-        nb_next<NW>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
+        nb_next<NW, !FULL>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
       }
 #pragma unroll
       for (int t = 0; t < 3; t++) rX[t] += mGN * gnV[t] - mG * gsV[t];
@@ -1327,7 +1355,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) { wnV[t] = shfl(wD[t], lane + 4); wn6V[t] = shfl(wD[t], lane + 2); }
       } else {
-        nb_next<NW>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
+        nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
       }
 #pragma unroll
       for (int c = 0; c < 5; c++) {
@@ -1425,7 +1453,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) { eL[t] = quad_bcast<2>(eD[t]); eA[t] = quad_bcast<3>(eD[t]); }
         double enV[3], en6V[3];
-        if constexpr (DIS) nb_next_dis(eD, enV, en6V, L.sEb[2], k, j, lane); else nb_next<NW>(eD, enV, en6V, L.sE, k, j, lane, has_next);
+        if constexpr (DIS) nb_next_dis(eD, enV, en6V, L.sEb[2], k, j, lane); else nb_next<NW, !FULL>(eD, enV, en6V, L.sE, k, j, lane, has_next);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
           const double en = enV[t], en6 = en6V[t];

@@ -197,6 +197,9 @@ static int mpc_known_answer_check(int N, int mode, KatResult* res) {
     a.seq_K = 1; a.queue = (int*)bq.p; a.qctr = (unsigned*)bc.p; a.seq_hot = ip + 9; a.seq_first = ip + 10; a.seq_groups = 1; a.seq_iters = ip + 11;
     lrc = qrw::mpc_sequence_launch(a, st.s);
   } else {
+#ifdef QRW_DEBUG_POISON
+    if (const char* sel = getenv("QRW_DEBUG_POISON_SEL")) a.pre_bin = atoi(sel);  // diagnostic build: mpc_kernel.hip, top of the kernel
+#endif
     lrc = qrw::mpc_launch(a, st.s);
   }
   if (lrc != 0) return -11;
@@ -617,6 +620,35 @@ extern "C" int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at) {
     HIP_OK(hipMemcpy(d, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice), "qrw_test_poke_aborted H2D");
   }
   return 0;
+}
+
+// Tests only: every compute unit's LDS filled with a bit pattern (one 160 000-byte workgroup at a time per compute unit, far more
+// workgroups than compute units), then the known-answer solve of mpc_solve_kernel for horizon N in launch form `mode` WITHOUT the
+// per-process cache of qrw_create.  A kernel that reads LDS it has not written (an operand "multiplied by zero", a lane whose
+// result is dropped later) passes on the zeros or small numbers other kernels usually leave behind and fails on NaN / Inf patterns.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long pattern, unsigned long long* sink) {
+  __shared__ unsigned long long s[20000];
+  for (int i = threadIdx.x; i < 20000; i += 256) s[i] = pattern;
+  __syncthreads();
+  if (sink && s[(threadIdx.x * 77 + blockIdx.x) % 20000] != pattern) *sink = 1ull;  // (keeps the stores alive)
+}
+extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t* iters, int32_t* status,
+                                     double* rho, double* err) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(-2, "qrw_test_known_answer: no HIP device");
+  std::lock_guard<std::mutex> lock(g_kat_mutex);
+  if (poison) {
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(4096), dim3(256), 0, nullptr, (unsigned long long)lds_pattern, (unsigned long long*)nullptr);
+    HIP_OK(hipGetLastError(), "qrw_test_known_answer poison launch");
+    HIP_OK(hipDeviceSynchronize(), "qrw_test_known_answer poison");
+  }
+  KatResult r;
+  const int rc = mpc_known_answer_check(N, mode, &r);
+  if (iters) *iters = r.iters;
+  if (status) *status = r.status;
+  if (rho) *rho = r.rho;
+  if (err) *err = r.err;
+  return rc;
 }
 
 extern "C" int qrw_mpc_get_order(qrw_handle h, int32_t* h_order, float* h_ema, int32_t* has_order) {

@@ -204,3 +204,22 @@ def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(sy
             assert bool((ctl.error_flag == 4).all()), (k, ctl.error_flag)
             assert float(r.tau_ff.abs().max()) == 0.0 and float(r.P.abs().max()) == 0.0 and bool((r.D == 0.1).all())
     assert raised_at == 10  # the next MPC call of the loop
+
+
+@pytest.mark.parametrize("pattern", [0xFFFFFFFFFFFFFFFF, 0x7FF0000000000000], ids=["nan", "inf"])
+def test_known_answers_do_not_depend_on_what_other_kernels_left_in_lds(pattern):
+    """Every compute unit's LDS filled with NaN / Inf, then the known-answer solve of every kind of horizon and launch form
+    (qrw_test_known_answer, no cache).  Round 4 found the runtime-horizon kernels (N < 16) multiplying a neighbour value of an
+    idle step -- derived from LDS nobody had written -- by a zero coefficient: right as long as the leftovers were finite, "solved"
+    after 25 iterations with NaN results when they were not (seen once as a failed qrw_create in a test run)."""
+    import ctypes as C
+    import qrw_hip
+
+    lib = qrw_hip.load_library()
+    for mode in (0, 1, 2):
+        for N in (1, 2, 5, 7, 8, 12, 15, 16, 17, 24, 31, 32):
+            if mode == 1 and N <= 16:
+                continue
+            it, st, rho, err = C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+            rc = lib.qrw_test_known_answer(N, mode, pattern, 1, C.byref(it), C.byref(st), C.byref(rho), C.byref(err))
+            assert rc == 0, (mode, N, rc, it.value, st.value, rho.value, err.value)

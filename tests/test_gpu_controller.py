@@ -289,6 +289,20 @@ def test_control_pre_without_mpc_inputs_leaves_the_rest_unchanged():
         assert torch.equal(full["xref"][:, :, :2], lazy["xref"][:, :, :2])
         if k > 1:
             assert bool((lazy["fsteps"] == -7.0).all()) and bool((lazy["gait"] == -7.0).all()) and bool((lazy["xref"][:, :, 2:] == -7.0).all())
+        # the planner's own copy of the footstep table (item 14, [N_gait][12]): rows 0 and 1 are kept current by the lazy call
+        # (row 1 is what updateNewContact takes at a gait change), the other rows wait for the next call with the MPC's inputs
+        for b in (0, B // 2, B - 1):
+            tf, tl = (e.planner_get(14, 12 * 20, b).reshape(20, 12) for e in engs)
+            assert np.array_equal(tf[:2], tl[:2]), (k, b)
+    # one call WITH the MPC's inputs brings the whole table (state copy and fsteps output) back to what the full sequence holds
+    args = (25, vref, _t(qf), _t(np.zeros((B, 18))), _t(np.zeros((B, 3))), 0)
+    outs[0] = engs[0].control_pre(*args, x_f_mpc=_t(x_f), out=outs[0])
+    outs[1] = engs[1].control_pre(*args, x_f_mpc=_t(x_f), out=outs[1])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0]["fsteps"], outs[1]["fsteps"]) and torch.equal(outs[0]["xref"], outs[1]["xref"])
+    assert torch.equal(outs[0]["gait"], outs[1]["gait"])
+    for b in (0, B // 2, B - 1):
+        assert np.array_equal(engs[0].planner_get(14, 12 * 20, b), engs[1].planner_get(14, 12 * 20, b)), b
 
 
 @pytest.mark.parametrize("mode", ["sync", "async_lag2"])
