@@ -130,6 +130,23 @@ static void base_inertia_diag(double Y[6]) {
 }
 
 
+// Tests only: every compute unit's LDS filled with a bit pattern (one 160 000-byte workgroup at a time per compute unit, far more
+// workgroups than compute units), then the known-answer solve of mpc_solve_kernel for horizon N in launch form `mode` WITHOUT the
+// per-process cache of qrw_create.  A kernel that reads LDS it has not written (an operand "multiplied by zero", a lane whose
+// result is dropped later) passes on the zeros or small numbers other kernels usually leave behind and fails on NaN / Inf patterns.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long pattern, unsigned long long* sink) {
+  __shared__ unsigned long long s[20000];
+  for (int i = threadIdx.x; i < 20000; i += 256) s[i] = pattern;
+  __syncthreads();
+  if (sink && s[(threadIdx.x * 77 + blockIdx.x) % 20000] != pattern) *sink = 1ull;  // (keeps the stores alive)
+}
+// QRW_DEBUG_POISON_LDS=1 (diagnostic; tests/README): every MPC launch of the library is preceded by that fill with NaN, on the
+// launch's stream -- the whole GPU test suite can then be run with "no kernel may depend on LDS leftovers" as an extra condition.
+static void debug_poison_lds(hipStream_t stream) {
+  static const bool on = getenv("QRW_DEBUG_POISON_LDS") && atoi(getenv("QRW_DEBUG_POISON_LDS")) != 0;
+  if (on) hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, stream, ~0ull, (unsigned long long*)nullptr);
+}
+
 // Known-answer check of THIS build of mpc_solve_kernel, run by qrw_create once per process, device and INSTANTIATION the
 // handle will launch (and by qrw_selftest_sweeps for all of them).  Why it exists: the kernel lives at the edge of the register
 // file, and one combination of compiler options has produced a library in which every solve diverges; the parity
@@ -426,10 +443,14 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
       HIP_OK(hipMemcpyAsync(h->pre_ctr + qrw::kPreErrWord, &forced, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream),
              "qrw_mpc_solve: forced give-up");
     }
+    debug_poison_lds((hipStream_t)stream);
     if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0 ||
         qrw::mpc_pre_error_flush(h->pre_ctr, h->pre_err_dev, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
-  } else if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  } else {
+    debug_poison_lds((hipStream_t)stream);
+    if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
+  }
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
   static const int order_min = getenv("QRW_ORDER_MIN") ? atoi(getenv("QRW_ORDER_MIN")) : 1024;  // experiments only
   if (h->cfg.batch > order_min) {
@@ -505,6 +526,7 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
   // are pre-filled with NaN (all-ones bytes) and the iteration counts with -1
   HIP_OK(hipMemsetAsync(d_out, 0xFF, need * 24 * (size_t)h->cfg.n_steps * sizeof(double), (hipStream_t)stream), "qrw_mpc_solve_sequence prefill");
   if (d_iters) HIP_OK(hipMemsetAsync(d_iters, 0xFF, need * sizeof(int32_t), (hipStream_t)stream), "qrw_mpc_solve_sequence prefill iters");
+  debug_poison_lds((hipStream_t)stream);
   if (qrw::mpc_sequence_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_mpc_solve_sequence: kernel launch failed", hipGetLastError());
   if (h->cfg.batch > 1024) {
@@ -622,16 +644,6 @@ extern "C" int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at) {
   return 0;
 }
 
-// Tests only: every compute unit's LDS filled with a bit pattern (one 160 000-byte workgroup at a time per compute unit, far more
-// workgroups than compute units), then the known-answer solve of mpc_solve_kernel for horizon N in launch form `mode` WITHOUT the
-// per-process cache of qrw_create.  A kernel that reads LDS it has not written (an operand "multiplied by zero", a lane whose
-// result is dropped later) passes on the zeros or small numbers other kernels usually leave behind and fails on NaN / Inf patterns.
-__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long pattern, unsigned long long* sink) {
-  __shared__ unsigned long long s[20000];
-  for (int i = threadIdx.x; i < 20000; i += 256) s[i] = pattern;
-  __syncthreads();
-  if (sink && s[(threadIdx.x * 77 + blockIdx.x) % 20000] != pattern) *sink = 1ull;  // (keeps the stores alive)
-}
 extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t* iters, int32_t* status,
                                      double* rho, double* err) {
   int ndev = 0;
