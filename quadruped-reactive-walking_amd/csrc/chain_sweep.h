@@ -128,7 +128,12 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
   auto fetch = [&](ChainOp& b, int p) {
     const double* q = pm + 2 * p * kSlot;
 #pragma unroll
+#ifdef QRW_EXPERIMENT_HALFREADS  // TIMING EXPERIMENT ONLY (wrong results): half of the sweeps' operand reads -- what a form with
+    // half the LDS instructions per step could gain at most (profiles/r4_n32_experiments.txt)
+    for (int c = 0; c < 12; c += 2) b.m[c] = b.m[c + 1] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
     for (int c = 0; c < 12; c++) b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
     b.r = pr[(2 * p + 1) * 12];
   };
 #ifdef QRW_EXPERIMENT_NODEP  // TIMING EXPERIMENT ONLY (wrong results): every step multiplies the sweep's first vector, so
@@ -189,12 +194,21 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   ChainOp b0, b1;
   auto fetch = [&](ChainOp& b, int p) {
     const qrw_d2* q = reinterpret_cast<const qrw_d2*>(pm + (LA - 2 * p - 1) * kSlot);
+#ifdef QRW_EXPERIMENT_HALFREADS
+#pragma unroll
+    for (int c = 0; c < 6; c += 2) {
+      const qrw_d2 v = q[c];
+      b.m[2 * c] = b.m[2 * c + 2] = v.x;
+      b.m[2 * c + 1] = b.m[2 * c + 3] = v.y;
+    }
+#else
 #pragma unroll
     for (int c = 0; c < 6; c++) {
       const qrw_d2 v = q[c];
       b.m[2 * c] = v.x;
       b.m[2 * c + 1] = v.y;
     }
+#endif
     b.r = pr[(LA - 2 * p - 1) * 12];
   };
   auto pair = [&](const ChainOp& b, int p) {

@@ -1723,7 +1723,7 @@ int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_
 
 // true for builds made with a timing-experiment macro: they compute wrong results on purpose, the self-test is skipped
 bool mpc_build_is_timing_experiment() {
-#if defined(QRW_EXPERIMENT_NOTERM) || defined(QRW_EXPERIMENT_NODEP)
+#if defined(QRW_EXPERIMENT_NOTERM) || defined(QRW_EXPERIMENT_NODEP) || defined(QRW_EXPERIMENT_HALFREADS)
   return true;
 #else
   return false;
