@@ -946,6 +946,11 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
   // (once or twice in all), and the row loop only selects and stores.  Same arithmetic per touch-down, same call order of
   // getPhaseDuration per foot (remainingTime_, `last_call`).  More than kTdMax touch-downs on some lane: the row-wise form.
   constexpr int kTdMax = 4;
+  // this foot's shoulder by selects on the kernel arguments (scalar registers): indexed with the lane's foot number the array is
+  // fetched from the kernel-argument segment in memory instead -- two dependent loads per touch-down, each waiting for every
+  // store issued before it (stores count in vmcnt on gfx9): 8 of the table's 16.7 k clocks
+  const double sh0 = (j == 0) ? a.shoulders[0] : (j == 1) ? a.shoulders[1] : (j == 2) ? a.shoulders[2] : a.shoulders[3];
+  const double sh1 = (j == 0) ? a.shoulders[4] : (j == 1) ? a.shoulders[5] : (j == 2) ? a.shoulders[6] : a.shoulders[7];
   const unsigned long long colj = (j == 0) ? cur.c[0] : (j == 1) ? cur.c[1] : (j == 2) ? cur.c[2] : cur.c[3];
   const unsigned long long anyrow = gm_any(cur) | 1ull;                 // (row 0 is not tested by the reference's walk)
   const int zrow = (~anyrow == 0ull) ? 64 : (__ffsll((long long)~anyrow) - 1);  // first all-zero row >= 1: the walk stops there
@@ -990,8 +995,8 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
         }
         nf[0] = fmax(fmin(nf[0], a.L), -a.L);
         nf[1] = fmax(fmin(nf[1], a.L), -a.L);
-        nf[0] += a.shoulders[0 * 4 + j];
-        nf[1] += a.shoulders[1 * 4 + j];
+        nf[0] += sh0;
+        nf[1] += sh1;
         nf[2] = 0.0;
         tdv[q][0] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
         tdv[q][1] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
@@ -1064,8 +1069,8 @@ __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu,
           }
           nf[0] = fmax(fmin(nf[0], a.L), -a.L);
           nf[1] = fmax(fmin(nf[1], a.L), -a.L);
-          nf[0] += a.shoulders[0 * 4 + j];
-          nf[1] += a.shoulders[1 * 4 + j];
+          nf[0] += sh0;
+          nf[1] += sh1;
           nf[2] = 0.0;
           nrow[0] = (c * nf[0] - sn * nf[1] + 0.0 * nf[2]) + dxp;
           nrow[1] = (sn * nf[0] + c * nf[1] + 0.0 * nf[2]) + dyp;
