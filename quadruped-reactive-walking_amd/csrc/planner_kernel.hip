@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "controller_glue.h"
+#include "qrw_device.h"
 #include "qrw_kernels.h"
 
 namespace qrw {
@@ -767,15 +768,10 @@ __device__ __forceinline__ double quadmax_d(double v) {
   o = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));
   return fmax(v, o);
 }
-template <int LANE>
-__device__ __forceinline__ double quad_bcast(double v) {  // lane LANE of each quad to its four lanes (quad_perm)
-  constexpr int kCtrl = LANE * 0x55;
-  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xF, 0xF, true),
-                          __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xF, 0xF, true));
-}
 }  // namespace
 
 __global__ __launch_bounds__(64) void control_pre_quad_kernel(ControllerArgs cu, PlannerArgs a, ControllerArgs cw, int with_wbc_inputs) {
+  kernarg_warm<(2 * sizeof(ControllerArgs) + sizeof(PlannerArgs) + 4 + 63) / 64>();
   const int tix = blockIdx.x * 64 + threadIdx.x;
   const int b = tix >> 2, j = tix & 3;
   if (b >= a.B) return;  // whole quads leave together

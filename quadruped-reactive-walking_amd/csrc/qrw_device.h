@@ -15,6 +15,46 @@ constexpr double kRhoEqOverIneq = 1e3;
 constexpr double kMinScaling = 1e-4;
 constexpr double kMaxScaling = 1e4;
 
+// Every 64-byte line of the kernel-argument segment touched by one scalar load each, all in flight together, one wait.  The
+// loop's kernels run one wavefront per SIMD and take 500-800 bytes of arguments that the compiler fetches where it needs them
+// (the scalar register file cannot hold them all): each such fetch is then a full trip to memory on the wavefront's critical
+// path (measured: 6.8 us of control_pre_quad_kernel's time appears / disappears with the argument segment in host / device
+// memory, HIP_FORCE_DEV_KERNARG).  After this the later fetches hit the scalar cache: control_pre_quad_kernel 19.4 -> 18.4 us per
+// 4096 robots; wbc16_kernel (400 bytes of arguments, fetched early anyway) gains nothing and does not use it.
+// ONE asm statement: the destination registers stay reserved until the wait (separate statements would let the compiler reuse
+// a destination while its load is still in flight -- seen as an intermittent fault in a first version).
+template <int LINES>
+__device__ __forceinline__ void kernarg_warm() {
+  static_assert(LINES >= 1 && LINES <= 16, "one register per line");
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int kLast = 64 * (LINES - 1);
+#define QRW_KO(i) ((64 * (i) < kLast) ? 64 * (i) : kLast)
+  int t0, t1, t2, t3, t4, t5, t6, t7;
+  if constexpr (LINES <= 8) {
+    asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
+                 "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+                 : "s"(ka), "n"(QRW_KO(0)), "n"(QRW_KO(1)), "n"(QRW_KO(2)), "n"(QRW_KO(3)), "n"(QRW_KO(4)), "n"(QRW_KO(5)), "n"(QRW_KO(6)),
+                   "n"(QRW_KO(7))
+                 : "memory");
+  } else {
+    int t8, t9, t10, t11, t12, t13, t14, t15;
+    asm volatile("s_load_dword %0, %16, %17\n\ts_load_dword %1, %16, %18\n\ts_load_dword %2, %16, %19\n\ts_load_dword %3, %16, %20\n\t"
+                 "s_load_dword %4, %16, %21\n\ts_load_dword %5, %16, %22\n\ts_load_dword %6, %16, %23\n\ts_load_dword %7, %16, %24\n\t"
+                 "s_load_dword %8, %16, %25\n\ts_load_dword %9, %16, %26\n\ts_load_dword %10, %16, %27\n\ts_load_dword %11, %16, %28\n\t"
+                 "s_load_dword %12, %16, %29\n\ts_load_dword %13, %16, %30\n\ts_load_dword %14, %16, %31\n\ts_load_dword %15, %16, %32\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10),
+                   "=&s"(t11), "=&s"(t12), "=&s"(t13), "=&s"(t14), "=&s"(t15)
+                 : "s"(ka), "n"(QRW_KO(0)), "n"(QRW_KO(1)), "n"(QRW_KO(2)), "n"(QRW_KO(3)), "n"(QRW_KO(4)), "n"(QRW_KO(5)), "n"(QRW_KO(6)),
+                   "n"(QRW_KO(7)), "n"(QRW_KO(8)), "n"(QRW_KO(9)), "n"(QRW_KO(10)), "n"(QRW_KO(11)), "n"(QRW_KO(12)), "n"(QRW_KO(13)),
+                   "n"(QRW_KO(14)), "n"(QRW_KO(15))
+                 : "memory");
+  }
+#undef QRW_KO
+}
+
 // ---- DPP quad operations on doubles (two 32-bit halves, 1 VALU op each, no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double v) {
