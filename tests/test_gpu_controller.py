@@ -431,3 +431,79 @@ def test_staggered_stream_groups_equal_single_handles_started_late(free):
             torch.cuda.synchronize()
             assert torch.equal(hist[t][sl], one._res["result"]), (g, t)
         assert torch.equal(flags[sl], one.error_flag)
+
+
+@pytest.mark.parametrize("cfg", ["default", "alt", "short_period"])
+def test_control_pre_quad_form_equals_the_thread_form_through_gait_changes(cfg, monkeypatch):
+    """qrw_control_pre's quad kernel (one quad per robot: touch-downs of the footstep table computed wave-together, mask arithmetic
+    for getPhaseDuration) against the one-thread-per-robot form (QRW_PRE_QUAD=0, the kernel the planner parity tests compare with
+    the CPU oracle) over 450 iterations in which every robot changes gait several times (pacing, bounding, walk, trot, static and
+    the 4-beat gait of code 5, per-robot codes), with and without the MPC's inputs: every output and the planner's persistent state."""
+    import torch
+
+    import qrw_hip
+
+    if cfg == "default":
+        B, N, kw, k_mpc = 21, 16, dict(), 10
+    elif cfg == "alt":  # 0.40 s gait on a 0.24 s horizon, 26 gait rows, 1 kHz loop
+        B, N, kw, k_mpc = 21, 12, dict(N_gait=26, T_gait=0.40, dt_wbc=0.001), 20
+    else:  # a 0.08 s gait period in 24 rows: up to six touch-downs per foot in the table (the quad form's row-wise fallback)
+        B, N, kw, k_mpc = 21, 4, dict(N_gait=24, T_gait=0.08), 10
+    Ng = kw.get("N_gait", 20)
+    rng = np.random.default_rng(77)
+    engs = [qrw_hip.Batch(B, N, **kw) for _ in range(2)]
+    for e in engs:
+        e.planner_init(k_mpc=k_mpc)
+        e.controller_init(_t(np.tile(Q_INIT, (B, 1))))
+    vref = rng.uniform(-0.5, 0.5, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.2])
+    vref[0, 5] = 0.0
+    qf = np.zeros((B, 19))
+    qf[:, 2], qf[:, 6], qf[:, 7:] = 0.2229, 1.0, Q_INIT
+    x_f = np.zeros((B, 24, N))
+    x_f[:, 2, :], x_f[:, 14::3, :] = 0.2229, 6.0
+    outs = [None, None]
+    keys = ("q", "v", "h_v", "v_ref", "oRh_oTh", "xref", "fsteps", "gait", "target", "feet_pva", "contacts", "x_f_wbc", "q_wbc", "b_v",
+            "f_cmd", "feet_cmd")
+    worst = 0.0
+    for k in range(450):
+        vf = np.zeros((B, 18))
+        vf[:, :6] = vref + rng.uniform(-0.05, 0.05, (B, 6))
+        rpy = rng.uniform(-0.02, 0.02, (B, 3))
+        qf[:, 0:2] += 0.002 * vref[:, 0:2]
+        code = np.zeros(B, np.int32)
+        if k in (37, 111, 180, 262, 333, 401):  # Gait::changeGait acts at k % k_mpc == 0 of a new phase; codes at any k are legal
+            code[:] = rng.integers(0, 6, B)
+        if k == 222:
+            code[:] = 4  # everybody static at once, then away from it again at 262
+        solve = (k % k_mpc == 0)
+        for e, eng in enumerate(engs):
+            monkeypatch.setenv("QRW_PRE_QUAD", "1" if e == 0 else "0")
+            c = _t(code).to(torch.int32) if code.any() else 0
+            outs[e] = eng.control_pre(k, _t(vref), _t(qf), _t(vf), _t(rpy), c, x_f_mpc=(None if solve else _t(x_f)), out=outs[e],
+                                      mpc_inputs=solve)
+        torch.cuda.synchronize()
+        for key in keys:
+            if not solve and key in ("fsteps", "gait"):
+                continue
+            if solve and key in ("x_f_wbc", "q_wbc", "b_v", "f_cmd", "feet_cmd"):
+                continue
+            a, b_ = outs[0][key].cpu().numpy(), outs[1][key].cpu().numpy()
+            if key == "xref" and not solve:
+                a, b_ = a[:, :, :2], b_[:, :, :2]
+            # (the two forms contract their fused multiply-adds differently; the swing polynomials amplify the last bit, as in the
+            # oracle comparison of tests/test_gpu_planner.py -- and the trajectory state is a recursion over hundreds of iterations;
+            # a wrong row or phase would show as 1e-2 and more)
+            loose = key in ("feet_pva", "feet_cmd")
+            assert np.allclose(a, b_, rtol=(1e-7 if loose else 1e-11), atol=(1e-6 if loose else 1e-13)), (k, key, np.abs(a - b_).max())
+            if not loose:
+                worst = max(worst, float(np.abs(a - b_).max()))
+        if k % 25 == 3 or solve:
+            for b in (0, 7, B - 1):
+                for item, n in ((0, 4 * Ng), (1, 4 * Ng), (2, 4 * Ng), (3, 1), (4, 1), (5, 1), (7, 12), (8, 12), (9, 12), (10, 12), (11, 12),
+                                (12, 4), (13, 4), (15, 12), (17, 12), (18, 2)):
+                    sa, sb = engs[0].planner_get(item, n, b), engs[1].planner_get(item, n, b)
+                    assert np.allclose(sa, sb, rtol=1e-7, atol=(1e-6 if item in (9, 10, 11) else 1e-12)), (k, b, item)
+                ta, tb = (e.planner_get(14, 12 * Ng, b).reshape(Ng, 12) for e in engs)
+                rows = Ng if solve else 2  # (rows >= 2 of the quad form's table wait for the next solving iteration)
+                assert np.allclose(ta[:rows], tb[:rows], rtol=1e-11, atol=1e-13), (k, b)
+    assert worst < 1e-9
