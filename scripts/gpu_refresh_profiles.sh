@@ -7,8 +7,6 @@ ROUND=${ROUND:-r3}
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-python3 bench.py > $OUT/${ROUND}_bench_line.json 2> $OUT/bench.err
-echo "bench done"
 python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_mixed.json 2> $OUT/bench32.err
 QRW_PREEMPT_CHUNK=0 python3 bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > $OUT/${ROUND}_bench_line_n32_mixed_unsliced.json 2>> $OUT/bench32.err
 echo "bench n32 done"
@@ -32,3 +30,8 @@ python3 scripts/trace_timed_avg.py $OUT/kernel_trace_b4096.csv 20 > $OUT/${ROUND
 python3 scripts/trace_timed_avg.py $OUT/kernel_trace_n32.csv 20 > $OUT/${ROUND}_timed_launch_avg_n32.txt
 for n in 16 32; do QRW_PHASES_N=$n python3 scripts/gpu_phases.py > $OUT/${ROUND}_mpc_phase_cycles_n$n.txt 2>/dev/null; done
 echo "phases done"
+# the ONE bench line last, with this call's counter summary + stamp in place (bench.py quotes roofline.traffic from profiles/ only when
+# the stamp matches the kernel sources)
+cp $OUT/${ROUND}_pmc_summary_bench_b4096.json $OUT/${ROUND}_pmc_stamp_bench_b4096.json $R/profiles/
+python3 bench.py > $OUT/${ROUND}_bench_line.json 2> $OUT/bench.err
+echo "bench done"
