@@ -28,7 +28,7 @@ class Controller_batch:
         return super().__new__(cls)
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
-                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
                  stagger=False, _out_views=None):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
 
@@ -44,9 +44,9 @@ class Controller_batch:
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
         on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
         compute units but `loop_cus`, the control loop (planners, glue, WBC) on a stream restricted to those
-        `loop_cus` units, so an iteration never queues behind a running solve (32, the default, gives the highest
-        free-running rate at batch 4096; batch / 64 -- one SIMD for every wavefront of the loop's kernels -- the lowest
-        iteration latency: 0.13 instead of 0.20 ms median at 14 % less rate, profiles/r4_async_loop_cus.txt).  A finished solve is adopted by the
+        `loop_cus` units, so an iteration never queues behind a running solve (default: batch / 64 -- one SIMD for every
+        wavefront of the loop's kernels, the lowest iteration latency, which is what the mode is for; 32 gives the highest
+        free-running rate at batch 4096: +14 % at 0.20 instead of 0.13 ms median, profiles/r4_async_loop_cus.txt).  A finished solve is adopted by the
         first iteration that finds its event complete (mpc_lag=None, what the reference's flag polling does), or --
         deterministic, for tests and replay -- exactly `mpc_lag` iterations after it was issued.
         The masked streams are ordinary (blocking) HIP streams: they synchronise with the legacy default stream, so call
@@ -87,6 +87,10 @@ class Controller_batch:
         self.mpc_lag = mpc_lag
         if self.multiprocessing:
             n_cu = qrw_hip.device_cu_count(device)
+            if loop_cus is None:
+                # one SIMD for every wavefront of the loop's kernels (a quad per robot: batch / 16 wavefronts, four SIMDs per compute
+                # unit), in steps of the 8 XCDs, at most a quarter of the chip: 64 compute units at batch 4096
+                loop_cus = min(max(8, 8 * ((self.B + 511) // 512)), n_cu // 4)
             loop_cus = max(1, min(int(loop_cus), n_cu - 1))
             self._s_loop = qrw_hip.CuStream(device, 0, loop_cus)
             self._s_mpc = qrw_hip.CuStream(device, loop_cus, n_cu - loop_cus)
@@ -252,7 +256,7 @@ class Controller_groups(Controller_batch):
     `stream_of(g)` (what bench.py's 1:10 figure does)."""
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
-                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=32, mpc_lag=None, fused=True, groups=None,
+                 h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
                  stagger=False, _out_views=None):
         import torch
 
