@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long patt
   __syncthreads();
   if (sink && s[(threadIdx.x * 77 + blockIdx.x) % 20000] != pattern) *sink = 1ull;  // (keeps the stores alive)
 }
-// QRW_DEBUG_POISON_LDS=1 (diagnostic; tests/README): every MPC launch of the library is preceded by that fill with NaN, on the
+// QRW_DEBUG_POISON_LDS=1 (diagnostic): every MPC / WBC / fused control-iteration launch of the library is preceded by that fill with NaN, on the
 // launch's stream -- the whole GPU test suite can then be run with "no kernel may depend on LDS leftovers" as an extra condition.
 static void debug_poison_lds(hipStream_t stream) {
   static const bool on = getenv("QRW_DEBUG_POISON_LDS") && atoi(getenv("QRW_DEBUG_POISON_LDS")) != 0;
@@ -737,6 +737,7 @@ extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_
   a.pgoals = d_pgoals; a.vgoals = d_vgoals; a.agoals = d_agoals;
   a.tau_ff = d_tau_ff; a.qdes = d_qdes; a.vdes = d_vdes; a.f_with_delta = d_f_with_delta;
   a.ddq_res = d_ddq_res; a.feet = d_feet;
+  debug_poison_lds((hipStream_t)stream);
   if (qrw::wbc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_wbc_compute: kernel launch failed", hipGetLastError());
   return 0;
 }
@@ -758,6 +759,7 @@ extern "C" int qrw_wbc_compute_result(qrw_handle h, const double* d_q, const dou
   a.tau_ff = d_tau_ff; a.qdes = d_qdes; a.vdes = d_vdes; a.f_with_delta = d_f_with_delta;
   a.ddq_res = d_ddq_res; a.feet = d_feet;
   a.c_cs = h->ctrl_st; a.c_qfilt = d_q_filt; a.c_vsecu = d_v_secu; a.c_result = d_result; a.c_err = d_error_flag;
+  debug_poison_lds((hipStream_t)stream);
   if (qrw::wbc_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_wbc_compute_result: kernel launch failed", hipGetLastError());
   return 0;
@@ -1187,6 +1189,7 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
   ctrl_common(h, cw, qrw::kCtrlWbcInputs);
   cw.in0 = d_x_f_mpc; cw.in1 = d_xref; cw.in2 = d_feet_pva; cw.in3 = d_v;
   cw.out0 = d_x_f_wbc; cw.out1 = d_q_wbc; cw.out2 = d_b_v; cw.out3 = d_f_cmd; cw.out4 = d_feet_cmd;
+  debug_poison_lds((hipStream_t)stream);
   if (qrw::control_pre_launch(cu, p, cw, d_x_f_mpc ? 1 : 0, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_control_pre: launch failed", hipGetLastError());
   return 0;
