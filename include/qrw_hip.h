@@ -130,6 +130,10 @@ int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at);
 int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t *iters, int32_t *status,
                           double *rho, double *err);
 
+/* Tests only: after the LDS / register-file fills of qrw_test_known_answer, what a new wavefront finds in an LDS word, v255 and a255
+ * it has not written: h_out3[0..2], all-ones when the fills are effective on this device. */
+int qrw_test_poison_probe(uint32_t *h_out3);
+
 /* Diagnostic: the block order the NEXT qrw_mpc_solve will use (h_order[i] = instance solved by workgroup i: a
  * permutation of 0..B-1, longest predicted solve first) and the moving average of iteration counts it was sorted by
  * (either may be NULL).  *has_order = 0 while no order exists (batch <= 1024, or before the first solve).  Synchronises

@@ -140,11 +140,21 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(unsigned long long patt
   __syncthreads();
   if (sink && s[(threadIdx.x * 77 + blockIdx.x) % 20000] != pattern) *sink = 1ull;  // (keeps the stores alive)
 }
+// ... and every vector register (256 architectural + 256 accumulation, one 512-register wavefront per SIMD, several rounds over the
+// chip): a new wavefront inherits whatever the last one left in the register file.
+#include "reg_poison_asm.h"
+__global__ __launch_bounds__(64, 1) void reg_poison_kernel(int* sink) {
+  asm volatile(QRW_REG_POISON_ASM ::: QRW_REG_POISON_CLOBBERS);
+  if (sink && threadIdx.x == 9999) *sink = 1;
+}
 // QRW_DEBUG_POISON_LDS=1 (diagnostic): every MPC / WBC / fused control-iteration launch of the library is preceded by that fill with NaN, on the
 // launch's stream -- the whole GPU test suite can then be run with "no kernel may depend on LDS leftovers" as an extra condition.
 static void debug_poison_lds(hipStream_t stream) {
   static const bool on = getenv("QRW_DEBUG_POISON_LDS") && atoi(getenv("QRW_DEBUG_POISON_LDS")) != 0;
-  if (on) hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, stream, ~0ull, (unsigned long long*)nullptr);
+  if (on) {
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, stream, ~0ull, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(reg_poison_kernel, dim3(4096), dim3(64), 0, stream, (int*)nullptr);
+  }
 }
 
 // Known-answer check of THIS build of mpc_solve_kernel, run by qrw_create once per process, device and INSTANTIATION the
@@ -644,6 +654,33 @@ extern "C" int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at) {
   return 0;
 }
 
+// Tests only: is the poisoning itself effective on this device?  After both fills a probe wavefront reads, without writing them first,
+// one LDS word, v255 and a255: out[0..2] (all-ones if the leftovers are what a new wavefront sees; the hardware clears neither).
+__global__ __launch_bounds__(64, 1) void poison_probe_kernel(unsigned* out) {
+  __shared__ unsigned s[40000];  // (the whole LDS of the compute unit: the word read below is inside the allocation)
+  unsigned v, acc, w;
+  const unsigned addr = (unsigned)(size_t)(&s[39000]) + 4u * threadIdx.x;
+  // (through asm: the compiler folds a plain read of never-written shared memory to a constant)
+  asm volatile("v_mov_b32 %0, v255\n\tv_accvgpr_read_b32 %1, a255\n\tds_read_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=v"(v), "=v"(acc), "=v"(w) : "v"(addr) : "v255", "a255", "memory");
+  if (threadIdx.x == 5) { out[0] = w; out[1] = v; out[2] = acc; }
+}
+extern "C" int qrw_test_poison_probe(uint32_t* h_out3) {
+  if (!h_out3) return fail(-1, "qrw_test_poison_probe: null argument");
+  std::lock_guard<std::mutex> lock(g_kat_mutex);
+  unsigned* d = nullptr;
+  HIP_OK(hipMalloc((void**)&d, 3 * sizeof(unsigned)), "qrw_test_poison_probe alloc");
+  hipMemset(d, 0, 3 * sizeof(unsigned));
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(4096), dim3(256), 0, nullptr, ~0ull, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(reg_poison_kernel, dim3(8192), dim3(64), 0, nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(poison_probe_kernel, dim3(1), dim3(64), 0, nullptr, d);
+  const hipError_t e = hipDeviceSynchronize();
+  hipMemcpy(h_out3, d, 3 * sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipFree(d);
+  HIP_OK(e, "qrw_test_poison_probe");
+  return 0;
+}
+
 extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t* iters, int32_t* status,
                                      double* rho, double* err) {
   int ndev = 0;
@@ -651,6 +688,7 @@ extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_patte
   std::lock_guard<std::mutex> lock(g_kat_mutex);
   if (poison) {
     hipLaunchKernelGGL(lds_poison_kernel, dim3(4096), dim3(256), 0, nullptr, (unsigned long long)lds_pattern, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(reg_poison_kernel, dim3(8192), dim3(64), 0, nullptr, (int*)nullptr);
     HIP_OK(hipGetLastError(), "qrw_test_known_answer poison launch");
     HIP_OK(hipDeviceSynchronize(), "qrw_test_known_answer poison");
   }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_mpc_get_order": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qrw_test_poke_aborted": (C.c_int, [_vp, C.c_int32]),
+    "qrw_test_poison_probe": (C.c_int, [C.POINTER(C.c_uint32)]),
     "qrw_test_known_answer": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qrw_mpc_get_slice_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

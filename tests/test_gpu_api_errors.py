@@ -208,7 +208,7 @@ def test_time_sliced_give_up_is_reported_at_the_next_call_and_stops_the_robot(sy
 
 @pytest.mark.parametrize("pattern", [0xFFFFFFFFFFFFFFFF, 0x7FF0000000000000], ids=["nan", "inf"])
 def test_known_answers_do_not_depend_on_what_other_kernels_left_in_lds(pattern):
-    """Every compute unit's LDS filled with NaN / Inf, then the known-answer solve of every kind of horizon and launch form
+    """Every compute unit's LDS filled with NaN / Inf (and every vector register with all-ones), then the known-answer solve of every kind of horizon and launch form
     (qrw_test_known_answer, no cache).  Round 4 found the runtime-horizon kernels (N < 16) multiplying a neighbour value of an
     idle step -- derived from LDS nobody had written -- by a zero coefficient: right as long as the leftovers were finite, "solved"
     after 25 iterations with NaN results when they were not (seen once as a failed qrw_create in a test run)."""
@@ -216,6 +216,9 @@ def test_known_answers_do_not_depend_on_what_other_kernels_left_in_lds(pattern):
     import qrw_hip
 
     lib = qrw_hip.load_library()
+    probe = (C.c_uint32 * 3)()
+    assert lib.qrw_test_poison_probe(probe) == 0
+    assert list(probe) == [0xFFFFFFFF] * 3, [hex(v) for v in probe]  # the fills are what a new wavefront sees (LDS, VGPR, AGPR)
     for mode in (0, 1, 2):
         for N in (1, 2, 5, 7, 8, 12, 15, 16, 17, 24, 31, 32):
             if mode == 1 and N <= 16:
