@@ -507,3 +507,25 @@ def test_control_pre_quad_form_equals_the_thread_form_through_gait_changes(cfg, 
                 rows = Ng if solve else 2  # (rows >= 2 of the quad form's table wait for the next solving iteration)
                 assert np.allclose(ta[:rows], tb[:rows], rtol=1e-11, atol=1e-13), (k, b)
     assert worst < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["sync", "async_lag3"])
+def test_closed_loop_does_not_depend_on_uninitialised_buffers(oracle_mod, monkeypatch, mode):
+    """Every torch.empty of the run (the controller's intermediate and output buffers on the device) comes back filled with NaN
+    (floating point) or -1 (integers) instead of whatever the allocator hands out: the closed loop must still match the chained
+    CPU oracles -- no kernel may read a buffer entry before something has written it (0 x leftover is only 0 while the leftover
+    is finite; see the LDS case of round 4, profiles/r4_lds_poison.txt)."""
+    import torch
+
+    real_empty = torch.empty
+
+    def poisoned_empty(*args, **kwargs):
+        t = real_empty(*args, **kwargs)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        elif t.dtype in (torch.int32, torch.int64):
+            t.fill_(-1)
+        return t
+
+    monkeypatch.setattr(torch, "empty", poisoned_empty)
+    _closed_loop(oracle_mod, mode, True, DEFAULT_CFG, 45)
