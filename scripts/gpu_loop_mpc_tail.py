@@ -1,0 +1,33 @@
+"""The MPC launches of the 1:10 closed loop (batch 4096): per solve the mean / max ADMM iteration count, the launch's duration
+(HIP events) and the two lower bounds max-count x tau and work / slots x tau -- is the loop's solve bound by its tail or by its work?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "quadruped-reactive-walking_amd")]
+import numpy as np, torch
+import synth
+from Controller import Controller_batch
+B, N = 4096, 16
+dev = torch.device("cuda:0")
+sb = synth.SyntheticBatch(B, N, N_gait=20, gaits=("trot",), n_seq=2)
+q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
+ctl = Controller_batch(B, q_init)
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+vref = torch.from_numpy(np.ascontiguousarray(scale * sb.vref)).to(dev)
+qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
+qf[:, 7:] = torch.from_numpy(q_init).to(dev)
+vf = torch.zeros((B, 18), dtype=torch.float64, device=dev); vf[:, :6] = vref
+rpy = torch.zeros((B, 3), dtype=torch.float64, device=dev); vs = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+TAU = 2.31e-3
+rows = []
+for k in range(160):
+    solve = (k % 10 == 0)
+    if solve:
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    r = ctl.compute(vref, qf, vf, rpy, vs)
+    if solve:
+        e1.record(); torch.cuda.synchronize()
+        it = ctl._b.mpc_stats()["iters"].astype(float)
+        rows.append((k, it.mean(), it.max(), e0.elapsed_time(e1), it.max() * TAU, it.sum() / 1024 * TAU))
+    qf[:, 7:].copy_(r.q_des); vf[:, 6:].copy_(r.v_des)
+print("k, mean it, max it, iteration with solve ms (incl. ~0.06 ms of loop kernels), max x tau, work/slots x tau")
+for r_ in rows: print("%4d %7.1f %6.0f %7.3f %7.3f %7.3f" % r_)
