@@ -528,6 +528,44 @@ class Batch:
             self._stream()), "qrw_wbc_compute_result")
         return out
 
+    def bind_iteration(self, pre, post):
+        """control_pre (an iteration that does not solve: no MPC inputs) + wbc_compute_result on FIXED output buffers -- the dicts
+        those two calls returned -- as one callable with the 34 output / hand-over pointers validated once: a control loop
+        passes the same buffers every iteration, and validating them again was most of compute()'s 40 us of host time.
+        step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu): the per-call tensors are validated as always."""
+        import torch
+
+        B, N = self.B, self.N
+        d, null = self._dev, _vp(0)
+        pre_ptrs = (d(pre["q"], (B, 19)), d(pre["v"], (B, 18)), d(pre["h_v"], (B, 6)), d(pre["v_ref"], (B, 6)),
+                    d(pre["oRh_oTh"], (B, 12)), d(pre["xref"], (B, 12, N + 1)), null, null, d(pre["target"], (B, 3, 4)),
+                    d(pre["feet_pva"], (B, 3, 3, 4)), d(pre["contacts"], (B, 4)), d(pre["x_f_wbc"], (B, 24)),
+                    d(pre["q_wbc"], (B, 19)), d(pre["b_v"], (B, 18)), d(pre["f_cmd"], (B, 12)), d(pre["feet_cmd"], (3, B, 3, 4)))
+        fc = pre["feet_cmd"]
+        post_a = (d(pre["q_wbc"], (B, 19)), d(pre["b_v"], (B, 18)), d(pre["f_cmd"], (B, 12)), d(pre["contacts"], (B, 4)),
+                  d(fc[0], (B, 3, 4)), d(fc[1], (B, 3, 4)), d(fc[2], (B, 3, 4)), d(post["tau_ff"], (B, 12)), d(post["qdes"], (B, 19)),
+                  d(post["vdes"], (B, 18)), d(post["f_with_delta"], (B, 12)), d(post["ddq_res"], (B, 6)), d(post["feet"], (B, 3, 3, 4)))
+        ef = post["error_flag"]
+        if not (ef.is_cuda and ef.dtype == torch.int32 and ef.is_contiguous() and tuple(ef.shape) == (B,)):
+            raise QrwError("error_flag: expected a contiguous int32 CUDA tensor of shape (B,)")
+        post_b = (d(post["result"], (B, 5, 12)), _vp(ef.data_ptr()))
+        keep = (pre, post, fc)  # the buffers stay alive as long as the callable does
+        f_pre, f_post, h, stream = self._lib.qrw_control_pre, self._lib.qrw_wbc_compute_result, self._handle, self._stream
+
+        def step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu):
+            _ = keep
+            st = stream()
+            if isinstance(code, torch.Tensor):
+                cptr, cs = _vp(code.data_ptr()), 0
+            else:
+                cptr, cs = null, int(code)
+            qf = d(q_filt, (B, 19))
+            _check(f_pre(h, int(k), d(joy_v_ref, (B, 6)), qf, d(v_filt, (B, 18)), d(rpy, (B, 3)), cptr, cs,
+                         d(x_f_mpc, (B, 24, N)), *pre_ptrs, st), "qrw_control_pre")
+            _check(f_post(h, *post_a, qf, d(v_secu, (B, 12)), *post_b, st), "qrw_wbc_compute_result")
+
+        return step
+
     # ------------------------------------------------ getters / diagnostics
     def mpc_gait(self, b=0):
         gait, S = np.empty((self.N_gait, 4)), np.empty(12 * self.N)
