@@ -118,11 +118,14 @@ class Controller_batch:
             return self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
-        self._s_loop.torch.wait_stream(caller)
-        with torch.cuda.stream(self._s_loop.torch):
-            r = self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
-        caller.wait_stream(self._s_loop.torch)
-        return r
+        loop = self._s_loop.torch
+        loop.wait_stream(caller)
+        # an iteration that does not solve is two library calls: given the loop's stream explicitly (no stream context to enter)
+        if not (self.fused and (self.k % self.k_mpc) != 0 and self._nonsolve_fast(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, loop)):
+            with torch.cuda.stream(loop):
+                self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+        caller.wait_stream(loop)
+        return self.result
 
     def _solve_async(self, plan, k):
         """scripts/MPC_Wrapper.py:150-180 (run_MPC_asynchronous): hand the planner outputs to the MPC and return."""
@@ -209,22 +212,10 @@ class Controller_batch:
             self._mpc_step(p, k)
             b.controller_wbc_inputs(self.x_f_mpc, p["xref"], p["feet_pva"], p["v"], out=p)
         else:
-            if self.multiprocessing:
-                self._poll(k)
-            if self._not_first_iter and self._mpc_out is not None:
-                self.x_f_mpc = self._mpc_out
-            else:
-                self._not_first_iter = True
-                self.x_f_mpc = self._mpc_default
-            # nobody reads the MPC's inputs on an iteration that does not solve: fsteps / gait / most of xref are not produced
-            if self._pre is not None and self._post is not None:
-                # both calls through the handle's pre-validated argument lists (qrw_hip.Batch.bind_iteration): same two launches
-                fast = self._fast
-                if fast is None or fast[0] is not self._pre or fast[1] is not self._post:
-                    self._fast = fast = (self._pre, self._post, b.bind_iteration(self._pre, self._post))
-                fast[2](k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, self.x_f_mpc, v_secu)
-                self.k += 1
+            if self._nonsolve_fast(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, None):
                 return self.result
+            self._pick_mpc_result(k)
+            # nobody reads the MPC's inputs on an iteration that does not solve: fsteps / gait / most of xref are not produced
             self._pre = p = b.control_pre(k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, x_f_mpc=self.x_f_mpc,
                                           out=self._pre, mpc_inputs=False)
         fc = p["feet_cmd"]
@@ -236,6 +227,30 @@ class Controller_batch:
             self.error_flag = w["error_flag"]
         self.k += 1
         return self.result
+
+    def _pick_mpc_result(self, k):
+        """scripts/Controller.py:246-253 on an iteration that does not solve: the newest finished result, or the default one."""
+        if self.multiprocessing:
+            self._poll(k)
+        if self._not_first_iter and self._mpc_out is not None:
+            self.x_f_mpc = self._mpc_out
+        else:
+            self._not_first_iter = True
+            self.x_f_mpc = self._mpc_default
+
+    def _nonsolve_fast(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, stream):
+        """An iteration that does not solve, through the handle's pre-validated argument lists (qrw_hip.Batch.bind_iteration: the
+        same two launches as control_pre + wbc_compute_result).  False until both calls have run once the ordinary way."""
+        if self._pre is None or self._post is None or self.result is None:
+            return False
+        fast = self._fast
+        if fast is None or fast[0] is not self._pre or fast[1] is not self._post or fast[2] is not stream:
+            self._fast = fast = (self._pre, self._post, stream, self._b.bind_iteration(self._pre, self._post, stream))
+        k = self.k
+        self._pick_mpc_result(k)
+        fast[3](k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, self.x_f_mpc, v_secu)
+        self.k = k + 1
+        return True
 
     def stop_parallel_loop(self):
         """scripts/MPC_Wrapper.py:300-306: drain the MPC stream and release both streams."""

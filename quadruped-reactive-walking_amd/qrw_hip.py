@@ -528,11 +528,12 @@ class Batch:
             self._stream()), "qrw_wbc_compute_result")
         return out
 
-    def bind_iteration(self, pre, post):
+    def bind_iteration(self, pre, post, stream=None):
         """control_pre (an iteration that does not solve: no MPC inputs) + wbc_compute_result on FIXED output buffers -- the dicts
         those two calls returned -- as one callable with the 34 output / hand-over pointers validated once: a control loop
         passes the same buffers every iteration, and validating them again was most of compute()'s 40 us of host time.
-        step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu): the per-call tensors are validated as always."""
+        step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu): the per-call tensors are validated as always.
+        stream: a torch stream to launch on whatever the current stream is (None: the caller's current stream, looked up per call)."""
         import torch
 
         B, N = self.B, self.N
@@ -550,11 +551,12 @@ class Batch:
             raise QrwError("error_flag: expected a contiguous int32 CUDA tensor of shape (B,)")
         post_b = (d(post["result"], (B, 5, 12)), _vp(ef.data_ptr()))
         keep = (pre, post, fc)  # the buffers stay alive as long as the callable does
-        f_pre, f_post, h, stream = self._lib.qrw_control_pre, self._lib.qrw_wbc_compute_result, self._handle, self._stream
+        f_pre, f_post, h, cur_stream = self._lib.qrw_control_pre, self._lib.qrw_wbc_compute_result, self._handle, self._stream
+        fixed = None if stream is None else _vp(stream.cuda_stream)
 
         def step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu):
             _ = keep
-            st = stream()
+            st = cur_stream() if fixed is None else fixed
             if isinstance(code, torch.Tensor):
                 cptr, cs = _vp(code.data_ptr()), 0
             else:
