@@ -18,7 +18,11 @@
  *     at max-iter or detects infeasibility is NOT an error: its status is reported per
  *     instance through qrw_*_get_stats and the (possibly NaN) result is passed through;
  *   - a handle owns the per-instance persistent solver state (warm start, rho, stale
- *     B/S entries — SURVEY.md §0.4) of ONE GPU's shard; single caller, not thread-safe.
+ *     B/S entries — SURVEY.md §0.4) of ONE GPU's shard; single caller, not thread-safe;
+ *   - synchronisation is per handle, never device-wide: a `_host` entry point or a getter waits for the last launch of the
+ *     state it reads (on whatever stream the caller launched it) and for its own copies on a private non-blocking stream of
+ *     the handle -- another handle's (or anybody's) work in flight on other streams is neither waited for nor stalled;
+ *   - entry points that exist for the test suite only are declared in include/qrw_hip_test.h.
  */
 #ifndef QRW_HIP_H_
 #define QRW_HIP_H_
@@ -118,21 +122,6 @@ int qrw_mpc_get_stats(qrw_handle h, int32_t *h_iters, int32_t *h_status, double 
  * y[44N] and of the last solve's scaling D[24N], E[44N], c (any may be NULL). Tests only. */
 int qrw_mpc_get_state(qrw_handle h, int32_t b, double *h_x, double *h_z, double *h_y, double *h_D, double *h_E,
                       double *h_c);
-
-/* Tests only: leave every instance of a time-sliced handle (N > 16, batch above the resident slots) as a launch whose queue
- * gave up would -- parked at iteration `parked_at`, the warm-start slots holding values that are not OSQP's iterates -- so that
- * the cold restart of the next qrw_mpc_solve can be checked without provoking a give-up.  -1 on other handles. */
-int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at);
-
-/* Tests only: (poison != 0) fill the LDS of every compute unit with `lds_pattern`, then run the known-answer solve of
- * mpc_solve_kernel for horizon N in launch form mode (0 one launch per call, 1 time-sliced: N > 16, 2 sequence) without the
- * per-process cache of qrw_create; 0 = the answer is right.  Catches reads of LDS the kernel has not written. */
-int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_pattern, int32_t poison, int32_t *iters, int32_t *status,
-                          double *rho, double *err);
-
-/* Tests only: after the LDS / register-file fills of qrw_test_known_answer, what a new wavefront finds in an LDS word, v255 and a255
- * it has not written: h_out3[0..2], all-ones when the fills are effective on this device. */
-int qrw_test_poison_probe(uint32_t *h_out3);
 
 /* Diagnostic: the block order the NEXT qrw_mpc_solve will use (h_order[i] = instance solved by workgroup i: a
  * permutation of 0..B-1, longest predicted solve first) and the moving average of iteration counts it was sorted by

@@ -20,10 +20,23 @@ class Result:
         self.P, self.D, self.q_des, self.v_des, self.tau_ff = (t[:, i] for i in range(5))
 
 
+AUTO_GROUPS_MIN_BATCH = 2048  # from this fleet size on, groups=None means two stream groups (below: one handle)
+
+
+def auto_groups(batch, groups=None):
+    """Number of stream groups a fleet of `batch` robots is stepped as when the caller does not say: robots are independent
+    (SURVEY.md 8(e)), a launch of the MPC ends with its longest solve while most of the chip is already idle, and from about
+    2048 robots on two groups in flight fill that tail (+10 % control steps/s at batch 4096; in the 1:10 loop, staggered,
+    the worst iteration of the fleet takes 3.2 instead of 5.6 ms).  Below that one handle is the faster form."""
+    if groups is not None:
+        return int(groups)
+    return 2 if (int(batch) >= AUTO_GROUPS_MIN_BATCH and int(batch) % 2 == 0) else 1
+
+
 class Controller_batch:
     def __new__(cls, batch, *args, groups=None, **kwargs):
-        # groups > 1: the fleet as independent stream groups, see Controller_groups (opt-in: measured below)
-        if cls is Controller_batch and (groups if groups is not None else 1) > 1:
+        # more than one group: the fleet as independent stream groups, see Controller_groups
+        if cls is Controller_batch and auto_groups(batch, groups) > 1:
             return super().__new__(Controller_groups)
         return super().__new__(cls)
 
@@ -86,6 +99,7 @@ class Controller_batch:
                 self._res = dict(result=_out_views["result"], error_flag=_out_views["error_flag"])
         self.multiprocessing = bool(multiprocessing)
         self.mpc_lag = mpc_lag
+        self.wbc_lanes = 16  # lanes per robot of the full WBC step (qrw_wbc_set_lanes): wbc16_kernel unless chosen otherwise below
         if self.multiprocessing:
             n_cu = qrw_hip.device_cu_count(device)
             if loop_cus is None:
@@ -101,6 +115,7 @@ class Controller_batch:
                 # (a quarter of the wavefronts, 1.55 x the length) is the faster one there (measured at batch 4096 on 32 compute
                 # units: 0.21 against 0.31 ms median paced latency)
                 self._b.wbc_set_lanes(4)
+                self.wbc_lanes = 4
             Ng = int(N_gait)
             mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=self.dev)
             self._snap = [(mk(self.B, 12, self.n_steps + 1), mk(self.B, Ng, 12)) for _ in range(3)]
@@ -282,10 +297,12 @@ class Controller_groups(Controller_batch):
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
-                 stagger=False, _out_views=None):
+                 stagger=None, _out_views=None):
         import torch
 
-        G = int(groups) if groups is not None else 2
+        G = auto_groups(batch, groups)
+        if stagger is None:
+            stagger = groups is None  # groups chosen from the fleet size come staggered (see Controller_batch.__init__)
         if G < 2 or int(batch) % G:
             raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (batch, G))
         self._torch = torch
@@ -307,6 +324,14 @@ class Controller_groups(Controller_batch):
         self.result = Result(self._fleet_result)
         qi = np.broadcast_to(np.asarray(q_init, dtype=np.float64).reshape(-1, 12), (self.B, 12))
         self._sl = [slice(g * self.Bs, (g + 1) * self.Bs) for g in range(G)]
+        # a group that starts late holds its initial posture until then: the gains the controller itself commands
+        # (scripts/Controller.py:306-307) around q_init, which is what the reference's main loop does with a robot whose
+        # controller has not started (scripts/main_solo12_control.py: PD on q_init before the loop)
+        for g in range(G):
+            if self._delay[g] > 0:
+                hold = np.zeros((self.Bs, 5, 12))
+                hold[:, 0], hold[:, 1], hold[:, 2] = 3.0, 0.2, qi[self._sl[g]]
+                self._fleet_result[self._sl[g]] = torch.from_numpy(hold).to(self.dev)
         for g in range(G):
             if (device, g) not in qrw_hip.StreamGroups._streams:
                 qrw_hip.StreamGroups._streams[(device, g)] = torch.cuda.Stream(self.dev)
@@ -323,7 +348,7 @@ class Controller_groups(Controller_batch):
         return self._sl[g]
 
     def group_started(self, g):
-        """False while a staggered group has not run its first iteration yet (its slice of the result is still zero)."""
+        """False while a staggered group has not run its first iteration yet (its slice of the result still holds q_init)."""
         return self._calls[g] > self._delay[g]
 
     def stream_of(self, g):
@@ -333,8 +358,8 @@ class Controller_groups(Controller_batch):
         """One control iteration (fleet tick) of group g alone: EVERY argument is that group's slice (contiguous, leading
         dimension batch / groups; a tensor joystick_code too), enqueued on the CURRENT stream -- call it under
         `torch.cuda.stream(ctl.stream_of(g))`, once per fleet tick and group.  With stagger=True the first
-        g * k_mpc / groups calls of group g do nothing (its robots have not started yet: its slice of the result stays zero,
-        its error flags 0) and return that slice."""
+        g * k_mpc / groups calls of group g do nothing (its robots have not started yet: its slice of the result holds q_init
+        with the controller's PD gains, its error flags are 0) and return that slice."""
         torch = self._torch
         t = self._calls[g]
         self._calls[g] = t + 1

@@ -71,8 +71,8 @@ class MPC_Wrapper:
             import torch
 
             self._torch = torch
-            self._b = qrw_hip.Batch(1, n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt),
-                                    T_gait=float(T_gait))
+            self._b = qrw_hip.shared_batch1("mpc", n_steps=self.n_steps, N_gait=self.N_gait, dt_mpc=float(dt),
+                                            T_gait=float(T_gait))
             self._stream = torch.cuda.Stream()
             self._event = None
             self._pending = None
@@ -165,17 +165,18 @@ class MPC_Wrapper_batch:
     iteration for every instance on the caller's stream; get_latest_result_batch() -> (B,24,N).
     Before the first solve it returns the reference's default result (scripts/MPC_Wrapper.py:64-71).
 
-    groups (default 1; opt-in): the fleet as independent stream groups, each with its own handle
-    and stream (qrw_hip.StreamGroups' stream pool): a launch ends with its longest solve while most of the chip is idle,
-    and with two groups in flight one group's stragglers run beside the other group's next solve.  Same results, bit for
-    bit.  solve_batch then returns at once; get_latest_result_batch() makes the caller's stream wait for the groups."""
+    groups (None = chosen from the fleet size: one handle below 2048 robots, two stream groups from there; 1 = one handle):
+    the fleet as independent stream groups, each with its own handle and stream (qrw_hip.StreamGroups' stream pool): a launch
+    ends with its longest solve while most of the chip is idle, and with two groups in flight one group's stragglers run
+    beside the other group's next solve (+10 % control steps/s at batch 4096).  Same results, bit for bit.  solve_batch
+    then returns at once; get_latest_result_batch() makes the caller's stream wait for the groups."""
 
     def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0, groups=None):
         import torch
 
         self._torch = torch
         self.B, self.n_steps, self.N_gait, self.device = int(batch), int(n_steps), int(N_gait), int(device)
-        G = int(groups) if groups is not None else 1
+        G = int(groups) if groups is not None else (2 if (self.B >= 2048 and self.B % 2 == 0) else 1)
         if G < 1 or self.B % G:
             raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (self.B, G))
         self.G, self.Bs = G, self.B // G

@@ -31,7 +31,7 @@ class wbc_controller():
 
     def __init__(self, dt, N_SIMULATION):
         self.dt = dt
-        self._b = qrw_hip.Batch(1, dt_wbc=float(dt))
+        self._b = qrw_hip.shared_batch1("wbc", dt_wbc=float(dt))  # the process-wide batch-1 handle (its WBC state)
         self.invKin = _InvKinView()
 
         self.M = np.zeros((18, 18))

@@ -128,27 +128,16 @@ __device__ __forceinline__ void chain_forward_paired(const double* sN, double* s
   auto fetch = [&](ChainOp& b, int p) {
     const double* q = pm + 2 * p * kSlot;
 #pragma unroll
-#ifdef QRW_EXPERIMENT_HALFREADS  // TIMING EXPERIMENT ONLY (wrong results): half of the sweeps' operand reads -- what a form with
-    // half the LDS instructions per step could gain at most (profiles/r4_n32_experiments.txt)
-    for (int c = 0; c < 12; c += 2) b.m[c] = b.m[c + 1] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
     for (int c = 0; c < 12; c++) b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#endif
     b.r = pr[(2 * p + 1) * 12];
   };
-#ifdef QRW_EXPERIMENT_NODEP  // TIMING EXPERIMENT ONLY (wrong results): every step multiplies the sweep's first vector, so
-  const double x_first = x;   // that no step depends on the one before it -- the most any re-association of the sweeps
-#define QRW_XIN x_first       // into shorter dependent chains could gain (scripts/gpu_iter_time.sh)
-#else
-#define QRW_XIN x
-#endif
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t1, computed in lanes 0..31
+    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
     x = swap_halves(x);           // now in lanes 32..63
     if (t1 == LB) pB = x;
     (t1 < LB ? ps_odd : ps_oddA)[t1 * 12] = x;
-    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t2, computed in lanes 32..63
+    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
     if (t2 < LA) {
       x = swap_halves(x);         // now in lanes 0..31
       ps_even[t2 * 12] = x;
@@ -188,35 +177,23 @@ __device__ __forceinline__ void chain_backward_paired(const double* sN, double* 
   double* ps_even = (own && h == 0) ? px : dump;          // even steps t < LA (stored after the exchange), both chains
   double* ps_lastA = (own && h == 1 && !rw) ? px : dump;  // step LA (even, not exchanged): chain A only
   double x = sX[m * 12 + i];
-#ifdef QRW_EXPERIMENT_NODEP
-  const double x_first = x;
-#endif
   ChainOp b0, b1;
   auto fetch = [&](ChainOp& b, int p) {
     const qrw_d2* q = reinterpret_cast<const qrw_d2*>(pm + (LA - 2 * p - 1) * kSlot);
-#ifdef QRW_EXPERIMENT_HALFREADS
-#pragma unroll
-    for (int c = 0; c < 6; c += 2) {
-      const qrw_d2 v = q[c];
-      b.m[2 * c] = b.m[2 * c + 2] = v.x;
-      b.m[2 * c + 1] = b.m[2 * c + 3] = v.y;
-    }
-#else
 #pragma unroll
     for (int c = 0; c < 6; c++) {
       const qrw_d2 v = q[c];
       b.m[2 * c] = v.x;
       b.m[2 * c + 1] = v.y;
     }
-#endif
     b.r = pr[(LA - 2 * p - 1) * 12];
   };
   auto pair = [&](const ChainOp& b, int p) {
     const int t1 = 2 * p + 1, t2 = t1 + 1;
-    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t1, computed in lanes 0..31
+    x = dpp_step12(b.r, x, b.m);  // step t1, computed in lanes 0..31
     x = swap_halves(x);
     ps_odd[(LA - t1) * 12] = x;
-    x = dpp_step12(b.r, QRW_XIN, b.m);  // step t2, computed in lanes 32..63
+    x = dpp_step12(b.r, x, b.m);  // step t2, computed in lanes 32..63
     if (t2 < LA) {
       x = swap_halves(x);
       ps_even[(LA - t2) * 12] = x;  // t2 < LA = LB + 1: both chains

@@ -1492,9 +1492,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           done = true;
         }
       }
-#ifndef QRW_EXPERIMENT_NOTERM  // timing experiments: every instance runs max_iter iterations (launch time / iterations is exact)
       if (done) break;
-#endif
       if (iter % 200 == 0) {  // adapt_rho on the SCALED residuals (compute_rho_estimate)
         pres_s = block_max<NW>(pres_s, L.sRed, wv, lane); nz_s = block_max<NW>(nz_s, L.sRed, wv, lane);
         nax_s = block_max<NW>(nax_s, L.sRed, wv, lane); dres_s = block_max<NW>(dres_s, L.sRed, wv, lane);
@@ -1719,15 +1717,6 @@ __global__ __launch_bounds__(64) void mpc_order_kernel(const int* __restrict__ i
 int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_t stream) {
   hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(64), 0, stream, iters, ema, order, B);
   return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-// true for builds made with a timing-experiment macro: they compute wrong results on purpose, the self-test is skipped
-bool mpc_build_is_timing_experiment() {
-#if defined(QRW_EXPERIMENT_NOTERM) || defined(QRW_EXPERIMENT_NODEP) || defined(QRW_EXPERIMENT_HALFREADS)
-  return true;
-#else
-  return false;
-#endif
 }
 
 // preemptive launch (N > 16 only): B * pre_cmax workgroups, the caller has reset pre_queue (-1) and pre_ctr (0) on the stream

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/qrw_hip.h"
+#include "../../include/qrw_hip_test.h"
 #include "../../include/qrw_solo12_model.h"
 #include "kat_table.h"
 #include "qrw_kernels.h"
@@ -76,7 +77,43 @@ struct qrw_handle_s {
   double* stage = nullptr;
   size_t stage_doubles = 0;
   int32_t* stage_i = nullptr;
+  // Synchronisation is per handle, never device-wide: the *_host entry points and the getters run their copies and launches on
+  // `host_stream` (private, non-blocking: it neither waits for nor stalls the legacy default stream or any other handle's
+  // streams) and wait for exactly two things -- the last launch of the state family they read (wait_family) and their own copies.
+  hipStream_t host_stream = nullptr;
+  hipStream_t last_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool launched[4] = {false, false, false, false};
 };
+
+namespace {
+// state families of a handle: which launches a getter has to wait for
+enum Family { kFamMpc = 0, kFamWbc = 1, kFamPlan = 2, kFamCtrl = 3 };
+inline void note_launch(qrw_handle_s* h, int fam, hipStream_t s) {
+  h->last_stream[fam] = s;
+  h->launched[fam] = true;
+}
+// Wait for the family's most recent launch (whatever stream the caller gave it), nothing else on the device.  A stream the caller
+// has destroyed since (its work had to be complete for that) is answered with an error by the runtime: cleared, and the
+// conservative device-wide wait taken instead.
+hipError_t wait_family(qrw_handle_s* h, int fam) {
+  if (!h->launched[fam] || h->last_stream[fam] == h->host_stream) return hipSuccess;  // (host_stream work is waited for below / was at its call)
+  hipError_t e = hipStreamSynchronize(h->last_stream[fam]);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  h->launched[fam] = false;
+  return hipDeviceSynchronize();
+}
+// live handles: qrw_stream_destroy forgets a destroyed stream in every handle that launched on it last
+std::mutex g_handles_mutex;
+std::vector<qrw_handle_s*> g_handles;
+inline hipError_t d2h(qrw_handle_s* h, void* dst, const void* src, size_t bytes) {
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->host_stream);
+}
+inline hipError_t h2d(qrw_handle_s* h, void* dst, const void* src, size_t bytes) {
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->host_stream);
+}
+inline hipError_t host_done(qrw_handle_s* h) { return hipStreamSynchronize(h->host_stream); }
+}  // namespace
 
 extern "C" const char* qrw_last_error(void) { return g_err.c_str(); }
 
@@ -193,17 +230,19 @@ static int mpc_known_answer_check(int N, int mode, KatResult* res) {
       hipMalloc(&bd.p, n_dbl * sizeof(double)) != hipSuccess || hipMalloc(&bq.p, q_ints * sizeof(int)) != hipSuccess ||
       hipMalloc(&bc.p, c_words * sizeof(unsigned)) != hipSuccess)
     return -10;
-  // blocking copies / memsets on the null stream of pageable host memory: complete when they return
-  hipMemcpy(bx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice);
-  hipMemcpy(bf.p, hf.data(), hf.size() * sizeof(double), hipMemcpyHostToDevice);
-  hipMemset(bo.p, 0xFF, hout.size() * sizeof(double));
-  hipMemset(bst.p, 0, (size_t)qrw::kMpcStItems * T * sizeof(double));
-  hipMemset(bg.p, 0, (size_t)Ng * 4 * sizeof(int));
-  hipMemset(bi.p, 0, n_int * sizeof(int));
-  hipMemset(bd.p, 0, n_dbl * sizeof(double));
-  hipMemset(bq.p, 0xFF, q_ints * sizeof(int));
-  hipMemset(bc.p, 0, c_words * sizeof(unsigned));
-  hipStreamSynchronize(nullptr);
+  // a private non-blocking stream: the check neither waits for nor stalls the work other streams of the process have queued
+  // (the fills and copies below are ordered before the launch by the stream itself)
+  struct Stream { hipStream_t s = nullptr; ~Stream() { if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); } } } st;
+  if (hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) != hipSuccess) return -10;
+  hipMemcpyAsync(bx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, st.s);
+  hipMemcpyAsync(bf.p, hf.data(), hf.size() * sizeof(double), hipMemcpyHostToDevice, st.s);
+  hipMemsetAsync(bo.p, 0xFF, hout.size() * sizeof(double), st.s);
+  hipMemsetAsync(bst.p, 0, (size_t)qrw::kMpcStItems * T * sizeof(double), st.s);
+  hipMemsetAsync(bg.p, 0, (size_t)Ng * 4 * sizeof(int), st.s);
+  hipMemsetAsync(bi.p, 0, n_int * sizeof(int), st.s);
+  hipMemsetAsync(bd.p, 0, n_dbl * sizeof(double), st.s);
+  hipMemsetAsync(bq.p, 0xFF, q_ints * sizeof(int), st.s);
+  hipMemsetAsync(bc.p, 0, c_words * sizeof(unsigned), st.s);
   qrw::MpcArgs a;
   memset(&a, 0, sizeof(a));
   a.B = 1; a.N = N; a.N_gait = Ng; a.dt = 0.02;
@@ -212,9 +251,6 @@ static int mpc_known_answer_check(int N, int mode, KatResult* res) {
   int* ip = (int*)bi.p; double* dp = (double*)bd.p;
   a.flags = ip; a.iters = ip + 1; a.status = ip + 2; a.rho_updates = ip + 3;
   a.rho_out = dp; a.pri = dp + 1; a.dua = dp + 2; a.prof = nullptr; a.order = nullptr;
-  // a private non-blocking stream: the check neither waits for nor stalls the work other streams of the process have queued
-  struct Stream { hipStream_t s = nullptr; ~Stream() { if (s) hipStreamDestroy(s); } } st;
-  if (hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking) != hipSuccess) return -10;
   int lrc;
   if (mode == kKatSliced) {
     a.pre_chunk = kChunk; a.pre_cmax = kCmax; a.pre_cap = kCmax - 1; a.pre_levels = kLevels; a.pre_bin = 200;
@@ -261,10 +297,6 @@ static int mpc_known_answer_once(int device, int N, int mode, KatResult* out) {
   if (device < 0 || device >= 64 || N < 1 || N > qrw::kMpcMaxN) return 0;
   std::lock_guard<std::mutex> lock(g_kat_mutex);
   signed char& state = g_kat_state[device][N][mode];
-  if (state == 0 && qrw::mpc_build_is_timing_experiment()) {
-    fprintf(stderr, "libqrw_hip: TIMING-EXPERIMENT BUILD (wrong results by construction), self-test skipped\n");
-    state = 1;
-  }
   if (state == 0) {
     const char* skip = getenv("QRW_SKIP_SELFTEST");  // escape hatch (e.g. bring-up on a new toolchain): say so, loudly
     if (skip && skip[0] == '1') {
@@ -307,6 +339,11 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
   h->cfg = *cfg;
   const size_t B = (size_t)cfg->batch;
   const int N = cfg->n_steps;
+  if (hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking) != hipSuccess) {
+    h->host_stream = nullptr;
+    qrw_destroy(h);
+    return fail(-10, "qrw_create: hipStreamCreateWithFlags", hipGetLastError());
+  }
 #define ALLOC(ptr, bytes)                                   \
   do {                                                      \
     hipError_t e__ = hipMalloc((void**)&(ptr), (bytes));    \
@@ -314,7 +351,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
       qrw_destroy(h);                                       \
       return fail(-10, "hipMalloc " #ptr, e__);             \
     }                                                       \
-    hipMemset((ptr), 0, (bytes));                           \
+    hipMemsetAsync((ptr), 0, (bytes), h->host_stream);      \
   } while (0)
   ALLOC(h->mpc_st, B * qrw::kMpcStItems * qrw::mpc_threads(N) * sizeof(double));
   ALLOC(h->mpc_gait, B * cfg->N_gait * 4 * sizeof(int));
@@ -385,13 +422,25 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
 #undef ALLOC
   base_inertia_diag(h->Y);
   if (const char* e16 = getenv("QRW_WBC16")) h->wbc_lanes16 = (e16[0] != '0');
-  HIP_OK(hipDeviceSynchronize(), "qrw_create sync");
+  {  // the zero fills above are complete before the caller can launch on any stream (this handle's own work only: no device-wide wait)
+    const hipError_t e = host_done(h);
+    if (e != hipSuccess) { qrw_destroy(h); return fail(-10, "qrw_create sync", e); }
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_handles_mutex);
+    g_handles.push_back(h);
+  }
   *out = h;
   return 0;
 }
 
 extern "C" int qrw_destroy(qrw_handle h) {
   if (!h) return 0;
+  {
+    std::lock_guard<std::mutex> lock(g_handles_mutex);
+    for (size_t i = 0; i < g_handles.size(); i++)
+      if (g_handles[i] == h) { g_handles.erase(g_handles.begin() + i); break; }
+  }
   DeviceScope dev_scope__(h->cfg.device);
   hipFree(h->mpc_st); hipFree(h->mpc_gait); hipFree(h->mpc_flags); hipFree(h->mpc_iters);
   hipFree(h->mpc_status); hipFree(h->mpc_rho_updates); hipFree(h->mpc_order); hipFree(h->mpc_ema); hipFree(h->mpc_rho); hipFree(h->mpc_pri);
@@ -401,6 +450,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   hipFree(h->pre_queue); hipFree(h->pre_ctr); hipFree(h->pause_it);
   if (h->pre_err_host) hipHostFree(h->pre_err_host);
   hipFree(h->stage); hipFree(h->stage_i);
+  if (h->host_stream) hipStreamDestroy(h->host_stream);
   delete h;
   return 0;
 }
@@ -461,6 +511,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
     debug_poison_lds((hipStream_t)stream);
     if (qrw::mpc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   }
+  note_launch(h, kFamMpc, (hipStream_t)stream);
   // next launch's block order = this solve's iteration counts, longest first (same stream: ordered after the solve)
   static const int order_min = getenv("QRW_ORDER_MIN") ? atoi(getenv("QRW_ORDER_MIN")) : 1024;  // experiments only
   if (h->cfg.batch > order_min) {
@@ -479,12 +530,14 @@ extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const doub
   double* dx = h->stage;
   double* df = dx + B * 12 * (N + 1);
   double* dout = df + B * Ng * 12;
-  HIP_OK(hipMemcpy(dx, h_xref, B * 12 * (N + 1) * sizeof(double), hipMemcpyHostToDevice), "H2D xref");
-  HIP_OK(hipMemcpy(df, h_fsteps, B * Ng * 12 * sizeof(double), hipMemcpyHostToDevice), "H2D fsteps");
-  if (h_num_iter) HIP_OK(hipMemcpy(h->stage_i, h_num_iter, B * sizeof(int32_t), hipMemcpyHostToDevice), "H2D num_iter");
-  int rc = qrw_mpc_solve(h, dx, df, h_num_iter ? h->stage_i : nullptr, num_iter_scalar, dout, nullptr);
+  HIP_OK(wait_family(h, kFamMpc), "qrw_mpc_solve_host: earlier solve of this handle");
+  HIP_OK(h2d(h, dx, h_xref, B * 12 * (N + 1) * sizeof(double)), "H2D xref");
+  HIP_OK(h2d(h, df, h_fsteps, B * Ng * 12 * sizeof(double)), "H2D fsteps");
+  if (h_num_iter) HIP_OK(h2d(h, h->stage_i, h_num_iter, B * sizeof(int32_t)), "H2D num_iter");
+  int rc = qrw_mpc_solve(h, dx, df, h_num_iter ? h->stage_i : nullptr, num_iter_scalar, dout, (void*)h->host_stream);
   if (rc) return rc;
-  HIP_OK(hipMemcpy(h_out, dout, B * 24 * N * sizeof(double), hipMemcpyDeviceToHost), "D2H result");
+  HIP_OK(d2h(h, h_out, dout, B * 24 * N * sizeof(double)), "D2H result");
+  HIP_OK(host_done(h), "qrw_mpc_solve_host sync");
   return 0;
 }
 
@@ -539,6 +592,7 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
   debug_poison_lds((hipStream_t)stream);
   if (qrw::mpc_sequence_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_mpc_solve_sequence: kernel launch failed", hipGetLastError());
+  note_launch(h, kFamMpc, (hipStream_t)stream);
   if (h->cfg.batch > 1024) {
     if (qrw::mpc_order_launch(h->mpc_iters, h->mpc_ema, h->mpc_order, h->cfg.batch, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve_sequence: order kernel launch failed", hipGetLastError());
@@ -552,10 +606,11 @@ extern "C" int qrw_mpc_sequence_error(qrw_handle h, int32_t* timed_out) {
   DeviceScope dev_scope__(h->cfg.device);
   *timed_out = 0;
   if (!h->seq_ctr) return 0;
-  // like every other getter: streams of qrw_stream_create are non-blocking, a plain copy would not wait for a sequence in flight
-  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_sequence_error sync");
+  // like every other getter: waits for this handle's last MPC launch (the sequence in flight), not for the device
+  HIP_OK(wait_family(h, kFamMpc), "qrw_mpc_sequence_error sync");
   unsigned c[qrw::kSeqQctrWords];
-  HIP_OK(hipMemcpy(c, h->seq_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_sequence_error");
+  HIP_OK(d2h(h, c, h->seq_ctr, sizeof(c)), "qrw_mpc_sequence_error");
+  HIP_OK(host_done(h), "qrw_mpc_sequence_error");
   *timed_out = (int32_t)c[qrw::kSeqErrWord];
   if (getenv("QRW_SEQ_STATS")) {
     fprintf(stderr, "qrw sequence: levels taken/queued");
@@ -577,17 +632,18 @@ extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double*
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_gait: bad argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const int N = h->cfg.n_steps, Ng = h->cfg.N_gait;
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  HIP_OK(wait_family(h, kFamMpc), "sync");
   if (h_gait) {
     std::vector<int> g(Ng * 4);
-    HIP_OK(hipMemcpy(g.data(), h->mpc_gait + (size_t)b * Ng * 4, Ng * 4 * sizeof(int), hipMemcpyDeviceToHost), "D2H gait");
+    HIP_OK(d2h(h, g.data(), h->mpc_gait + (size_t)b * Ng * 4, Ng * 4 * sizeof(int)), "D2H gait");
+    HIP_OK(host_done(h), "D2H gait");
     for (int i = 0; i < Ng * 4; i++) h_gait[i] = (double)g[i];
   }
   if (h_Sgait) {
     const int T = qrw::mpc_threads(N);
     std::vector<double> s(3 * T);
-    HIP_OK(hipMemcpy(s.data(), h->mpc_st + ((size_t)b * qrw::kMpcStItems + qrw::kStS) * T, 3 * T * sizeof(double),
-                     hipMemcpyDeviceToHost), "D2H S");
+    HIP_OK(d2h(h, s.data(), h->mpc_st + ((size_t)b * qrw::kMpcStItems + qrw::kStS) * T, 3 * T * sizeof(double)), "D2H S");
+    HIP_OK(host_done(h), "D2H S");
     for (int k = 0; k < N; k++)
       for (int j = 0; j < 4; j++)
         for (int t = 0; t < 3; t++) h_Sgait[12 * k + 3 * j + t] = s[t * T + 4 * k + j];
@@ -600,18 +656,20 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   if (!h) return fail(-1, "qrw_mpc_get_stats: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  HIP_OK(wait_family(h, kFamMpc), "sync");  // this handle's last solve only: another handle's launch in flight is not waited for
   if (h->pre_ctr) {  // a time-sliced launch whose queue gave up (never expected) left solves unfinished: say so, loudly
     unsigned c[qrw::kPreCtrWords];
-    HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "D2H pre_ctr");
+    HIP_OK(d2h(h, c, h->pre_ctr, sizeof(c)), "D2H pre_ctr");
+    HIP_OK(host_done(h), "D2H pre_ctr");
     if (c[qrw::kPreErrWord] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
                                      "or overran its queue; results of that call are incomplete");
   }
-  if (h_iters) HIP_OK(hipMemcpy(h_iters, h->mpc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
-  if (h_status) HIP_OK(hipMemcpy(h_status, h->mpc_status, B * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
-  if (h_rho) HIP_OK(hipMemcpy(h_rho, h->mpc_rho, B * sizeof(double), hipMemcpyDeviceToHost), "D2H rho");
-  if (h_pri_res) HIP_OK(hipMemcpy(h_pri_res, h->mpc_pri, B * sizeof(double), hipMemcpyDeviceToHost), "D2H pri");
-  if (h_dua_res) HIP_OK(hipMemcpy(h_dua_res, h->mpc_dua, B * sizeof(double), hipMemcpyDeviceToHost), "D2H dua");
+  if (h_iters) HIP_OK(d2h(h, h_iters, h->mpc_iters, B * sizeof(int)), "D2H iters");
+  if (h_status) HIP_OK(d2h(h, h_status, h->mpc_status, B * sizeof(int)), "D2H status");
+  if (h_rho) HIP_OK(d2h(h, h_rho, h->mpc_rho, B * sizeof(double)), "D2H rho");
+  if (h_pri_res) HIP_OK(d2h(h, h_pri_res, h->mpc_pri, B * sizeof(double)), "D2H pri");
+  if (h_dua_res) HIP_OK(d2h(h, h_dua_res, h->mpc_dua, B * sizeof(double)), "D2H dua");
+  HIP_OK(host_done(h), "qrw_mpc_get_stats");
   return 0;
 }
 
@@ -625,9 +683,10 @@ extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* c
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = 0;
   *h_takers = *h_finished = 0;
   if (!h->pre_ctr) return 0;
-  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_slice_stats sync");
+  HIP_OK(wait_family(h, kFamMpc), "qrw_mpc_get_slice_stats sync");
   unsigned c[qrw::kPreCtrWords];
-  HIP_OK(hipMemcpy(c, h->pre_ctr, sizeof(c), hipMemcpyDeviceToHost), "qrw_mpc_get_slice_stats");
+  HIP_OK(d2h(h, c, h->pre_ctr, sizeof(c)), "qrw_mpc_get_slice_stats");
+  HIP_OK(host_done(h), "qrw_mpc_get_slice_stats");
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = c[qrw::kPreLevelWord + 2 * l + 1];
   *h_takers = c[qrw::kPreTicketWord];
   *h_finished = c[qrw::kPreDoneWord];
@@ -638,7 +697,7 @@ extern "C" int qrw_test_poke_aborted(qrw_handle h, int32_t parked_at) {
   if (!h || parked_at < 1) return fail(-1, "qrw_test_poke_aborted: bad argument");
   if (!h->pause_it || !mpc_time_sliced(h)) return fail(-1, "qrw_test_poke_aborted: not a time-sliced handle");
   DeviceScope dev_scope__(h->cfg.device);
-  HIP_OK(hipDeviceSynchronize(), "qrw_test_poke_aborted sync");
+  HIP_OK(wait_family(h, kFamMpc), "qrw_test_poke_aborted sync");
   const size_t B = h->cfg.batch, T = qrw::mpc_threads(h->cfg.n_steps);
   std::vector<int> pit(B, parked_at);
   HIP_OK(hipMemcpy(h->pause_it, pit.data(), B * sizeof(int), hipMemcpyHostToDevice), "qrw_test_poke_aborted pause_it");
@@ -704,11 +763,12 @@ extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_patte
 extern "C" int qrw_mpc_get_order(qrw_handle h, int32_t* h_order, float* h_ema, int32_t* has_order) {
   if (!h || !has_order) return fail(-1, "qrw_mpc_get_order: null argument");
   DeviceScope dev_scope__(h->cfg.device);
-  HIP_OK(hipDeviceSynchronize(), "qrw_mpc_get_order sync");
+  HIP_OK(wait_family(h, kFamMpc), "qrw_mpc_get_order sync");
   *has_order = h->mpc_have_order ? 1 : 0;
   const size_t B = h->cfg.batch;
-  if (h_order) HIP_OK(hipMemcpy(h_order, h->mpc_order, B * sizeof(int32_t), hipMemcpyDeviceToHost), "qrw_mpc_get_order");
-  if (h_ema) HIP_OK(hipMemcpy(h_ema, h->mpc_ema, B * sizeof(float), hipMemcpyDeviceToHost), "qrw_mpc_get_order ema");
+  if (h_order) HIP_OK(d2h(h, h_order, h->mpc_order, B * sizeof(int32_t)), "qrw_mpc_get_order");
+  if (h_ema) HIP_OK(d2h(h, h_ema, h->mpc_ema, B * sizeof(float)), "qrw_mpc_get_order ema");
+  HIP_OK(host_done(h), "qrw_mpc_get_order");
   return 0;
 }
 
@@ -719,9 +779,9 @@ extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h
   const int N = h->cfg.n_steps;
   const int T = qrw::mpc_threads(N);
   std::vector<double> s((size_t)qrw::kMpcStItems * T);
-  HIP_OK(hipDeviceSynchronize(), "sync");
-  HIP_OK(hipMemcpy(s.data(), h->mpc_st + (size_t)b * qrw::kMpcStItems * T, s.size() * sizeof(double),
-                   hipMemcpyDeviceToHost), "D2H state");
+  HIP_OK(wait_family(h, kFamMpc), "sync");
+  HIP_OK(d2h(h, s.data(), h->mpc_st + (size_t)b * qrw::kMpcStItems * T, s.size() * sizeof(double)), "D2H state");
+  HIP_OK(host_done(h), "D2H state");
   auto at = [&](int item, int k, int j) { return s[(size_t)item * T + 4 * k + j]; };
   for (int k = 0; k < N; k++)
     for (int j = 0; j < 4; j++) {
@@ -777,6 +837,7 @@ extern "C" int qrw_wbc_compute(qrw_handle h, const double* d_q, const double* d_
   a.ddq_res = d_ddq_res; a.feet = d_feet;
   debug_poison_lds((hipStream_t)stream);
   if (qrw::wbc_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_wbc_compute: kernel launch failed", hipGetLastError());
+  note_launch(h, kFamWbc, (hipStream_t)stream);
   return 0;
 }
 
@@ -800,6 +861,8 @@ extern "C" int qrw_wbc_compute_result(qrw_handle h, const double* d_q, const dou
   debug_poison_lds((hipStream_t)stream);
   if (qrw::wbc_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_wbc_compute_result: kernel launch failed", hipGetLastError());
+  note_launch(h, kFamWbc, (hipStream_t)stream);
+  note_launch(h, kFamCtrl, (hipStream_t)stream);
   return 0;
 }
 
@@ -811,7 +874,7 @@ struct Stager {
   explicit Stager(qrw_handle hh) : h(hh) {}
   double* in(const double* src, size_t n) {
     double* d = out(n);
-    if (d && src && hipMemcpy(d, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    if (d && src && h2d(h, d, src, n * sizeof(double)) != hipSuccess) ok = false;
     return d;
   }
   double* out(size_t n) {
@@ -820,9 +883,10 @@ struct Stager {
     off += n;
     return d;
   }
+  // (asynchronous on the handle's host stream: the caller ends with host_done)
   bool back(double* dst, const double* d, size_t n) {
     if (!dst) return true;
-    return hipMemcpy(dst, d, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    return d2h(h, dst, d, n * sizeof(double)) == hipSuccess;
   }
 };
 }  // namespace
@@ -834,18 +898,19 @@ extern "C" int qrw_wbc_compute_host(qrw_handle h, const double* h_q, const doubl
   if (!h) return fail(-1, "qrw_wbc_compute_host: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
+  HIP_OK(wait_family(h, kFamWbc), "qrw_wbc_compute_host: earlier WBC step of this handle");
   Stager s(h);
   double *q = s.in(h_q, B * 19), *dq = s.in(h_dq, B * 18), *f = s.in(h_f_cmd, B * 12), *c = s.in(h_contacts, B * 4);
   double *pg = s.in(h_pgoals, B * 12), *vg = s.in(h_vgoals, B * 12), *ag = s.in(h_agoals, B * 12);
   double *tau = s.out(B * 12), *qd = s.out(B * 19), *vd = s.out(B * 18), *fw = s.out(B * 12), *dd = s.out(B * 6),
          *ft = s.out(B * 36);
   if (!s.ok) return fail(-12, "qrw_wbc_compute_host: staging failed");
-  int rc = qrw_wbc_compute(h, q, dq, f, c, pg, vg, ag, tau, qd, vd, fw, dd, ft, nullptr);
+  int rc = qrw_wbc_compute(h, q, dq, f, c, pg, vg, ag, tau, qd, vd, fw, dd, ft, (void*)h->host_stream);
   if (rc) return rc;
-  HIP_OK(hipDeviceSynchronize(), "wbc sync");
   if (!(s.back(h_tau_ff, tau, B * 12) && s.back(h_qdes, qd, B * 19) && s.back(h_vdes, vd, B * 18) &&
         s.back(h_f_with_delta, fw, B * 12) && s.back(h_ddq_res, dd, B * 6) && s.back(h_feet, ft, B * 36)))
     return fail(-12, "qrw_wbc_compute_host: D2H failed");
+  HIP_OK(host_done(h), "wbc sync");
   return 0;
 }
 
@@ -854,12 +919,14 @@ extern "C" int qrw_wbc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
   if (!h) return fail(-1, "qrw_wbc_get_stats: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
-  HIP_OK(hipDeviceSynchronize(), "sync");
-  if (h_iters) HIP_OK(hipMemcpy(h_iters, h->wbc_iters, B * sizeof(int), hipMemcpyDeviceToHost), "D2H iters");
-  if (h_status) HIP_OK(hipMemcpy(h_status, h->wbc_status, B * sizeof(int), hipMemcpyDeviceToHost), "D2H status");
+  HIP_OK(wait_family(h, kFamWbc), "sync");
+  if (h_iters) HIP_OK(d2h(h, h_iters, h->wbc_iters, B * sizeof(int)), "D2H iters");
+  if (h_status) HIP_OK(d2h(h, h_status, h->wbc_status, B * sizeof(int)), "D2H status");
+  HIP_OK(host_done(h), "qrw_wbc_get_stats");
   if (h_rho || h_k_since_contact) {
     std::vector<double> s(B * qrw::kWbcStItems);
-    HIP_OK(hipMemcpy(s.data(), h->wbc_st, s.size() * sizeof(double), hipMemcpyDeviceToHost), "D2H wbc state");
+    HIP_OK(d2h(h, s.data(), h->wbc_st, s.size() * sizeof(double)), "D2H wbc state");
+    HIP_OK(host_done(h), "D2H wbc state");
     for (size_t b = 0; b < B; b++) {
       if (h_rho) h_rho[b] = s[b * qrw::kWbcStItems + qrw::kWsRho];
       if (h_k_since_contact)
@@ -881,11 +948,11 @@ extern "C" int qrw_fixed_feet_host(qrw_handle h, const double* h_q12, const doub
   a.in0 = s.in(h_q12, B * 12); a.in1 = s.in(h_dq12, B * 12);
   a.out0 = s.out(B * 12); a.out1 = s.out(B * 12); a.out2 = s.out(B * 12); a.out3 = s.out(B * 12); a.out4 = s.out(B * 144);
   if (!s.ok) return fail(-12, "qrw_fixed_feet_host: staging failed");
-  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_fixed_feet_host: launch failed", hipGetLastError());
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (qrw::wbc_launch(a, h->host_stream) != 0) return fail(-11, "qrw_fixed_feet_host: launch failed", hipGetLastError());
   if (!(s.back(h_posf, a.out0, B * 12) && s.back(h_vf, a.out1, B * 12) && s.back(h_wf, a.out2, B * 12) &&
         s.back(h_af, a.out3, B * 12) && s.back(h_Jf, a.out4, B * 144)))
     return fail(-12, "qrw_fixed_feet_host: D2H failed");
+  HIP_OK(host_done(h), "sync");
   return 0;
 }
 
@@ -905,10 +972,10 @@ extern "C" int qrw_invkin_host(qrw_handle h, const double* h_contacts, const dou
   a.in6 = s.in(h_wf, B * 12); a.in7 = s.in(h_af, B * 12); a.in8 = s.in(h_Jf, B * 144);
   a.out0 = s.out(B * 12); a.out1 = s.out(B * 12); a.out2 = s.out(B * 12);
   if (!s.ok) return fail(-12, "qrw_invkin_host: staging failed");
-  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_invkin_host: launch failed", hipGetLastError());
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (qrw::wbc_launch(a, h->host_stream) != 0) return fail(-11, "qrw_invkin_host: launch failed", hipGetLastError());
   if (!(s.back(h_ddq, a.out0, B * 12) && s.back(h_dq_cmd, a.out1, B * 12) && s.back(h_q_step, a.out2, B * 12)))
     return fail(-12, "qrw_invkin_host: D2H failed");
+  HIP_OK(host_done(h), "sync");
   return 0;
 }
 
@@ -917,6 +984,7 @@ extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_J
   if (!h || !h_M || !h_Jc || !h_f_cmd || !h_RNEA) return fail(-1, "qrw_qpwbc_host: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch;
+  HIP_OK(wait_family(h, kFamWbc), "qrw_qpwbc_host: earlier WBC step of this handle");
   Stager s(h);
   qrw::WbcArgs a;
   wbc_common(h, a);
@@ -934,13 +1002,14 @@ extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_J
   if (!diagonal) d_yinv = s.out(B * 36);
   if (!s.ok) return fail(-12, "qrw_qpwbc_host: staging failed");
   if (d_yinv) {
-    if (qrw::pinv6_launch(a.in0, d_yinv, (int)B, nullptr) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
+    if (qrw::pinv6_launch(a.in0, d_yinv, (int)B, h->host_stream) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
     a.in4 = d_yinv;
   }
-  if (qrw::wbc_launch(a, nullptr) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  if (qrw::wbc_launch(a, h->host_stream) != 0) return fail(-11, "qrw_qpwbc_host: launch failed", hipGetLastError());
+  note_launch(h, kFamWbc, h->host_stream);
   if (!(s.back(h_f_res, a.out0, B * 12) && s.back(h_ddq_res, a.out1, B * 6) && s.back(h_H, a.out2, B * 144)))
     return fail(-12, "qrw_qpwbc_host: D2H failed");
+  HIP_OK(host_done(h), "sync");
   return 0;
 }
 
@@ -987,8 +1056,9 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
 extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] */) {
   if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
-  HIP_OK(hipDeviceSynchronize(), "sync");
-  HIP_OK(hipMemcpy(h_prof, h->mpc_prof, (size_t)h->cfg.batch * qrw::kMpcProfItems * sizeof(double), hipMemcpyDeviceToHost), "D2H prof");
+  HIP_OK(wait_family(h, kFamMpc), "sync");
+  HIP_OK(d2h(h, h_prof, h->mpc_prof, (size_t)h->cfg.batch * qrw::kMpcProfItems * sizeof(double)), "D2H prof");
+  HIP_OK(host_done(h), "D2H prof");
   return 0;
 }
 
@@ -1018,6 +1088,7 @@ extern "C" int qrw_planner_init(qrw_handle h, const qrw_planner_config* pc, void
   planner_common(h, a);
   a.mode = qrw::kPlanInit;
   if (qrw::planner_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_planner_init: launch failed", hipGetLastError());
+  note_launch(h, kFamPlan, (hipStream_t)stream);
   h->plan_ready = true;
   return 0;
 }
@@ -1040,6 +1111,7 @@ extern "C" int qrw_planner_step(qrw_handle h, int32_t k, const double* d_q7, int
   a.xref = d_xref; a.fsteps = d_fsteps; a.gait = d_gait; a.target = d_target; a.feet_pva = d_feet_pva;
   a.contacts = d_contacts;
   if (qrw::planner_launch(a, (hipStream_t)stream) != 0) return fail(-11, "qrw_planner_step: launch failed", hipGetLastError());
+  note_launch(h, kFamPlan, (hipStream_t)stream);
   return 0;
 }
 
@@ -1050,6 +1122,7 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
   if (!h || !h->plan_ready) return fail(-1, "qrw_planner_call_host: planner not initialised");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
+  HIP_OK(wait_family(h, kFamPlan), "qrw_planner_call_host: earlier planner step of this handle");
   Stager s(h);
   qrw::PlannerArgs a;
   planner_common(h, a);
@@ -1065,11 +1138,12 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
   a.target = h_target ? s.out(B * 12) : nullptr;
   a.feet_pva = h_feet_pva ? s.out(B * 36) : nullptr;
   if (!s.ok) return fail(-12, "qrw_planner_call_host: staging failed");
-  if (qrw::planner_launch(a, nullptr) != 0) return fail(-11, "qrw_planner_call_host: launch failed", hipGetLastError());
-  HIP_OK(hipDeviceSynchronize(), "planner sync");
+  if (qrw::planner_launch(a, h->host_stream) != 0) return fail(-11, "qrw_planner_call_host: launch failed", hipGetLastError());
+  note_launch(h, kFamPlan, h->host_stream);
   if (!(s.back(h_xref, a.xref, B * 12 * (N + 1)) && s.back(h_fsteps, a.fsteps, B * Ng * 12) && s.back(h_gait, a.gait, B * Ng * 4) &&
         s.back(h_target, a.target, B * 12) && s.back(h_feet_pva, a.feet_pva, B * 36)))
     return fail(-12, "qrw_planner_call_host: D2H failed");
+  HIP_OK(host_done(h), "planner sync");
   return 0;
 }
 
@@ -1078,12 +1152,13 @@ extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int3
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
   const int off = qrw::planner_item_offset(h->cfg.N_gait, which);
   const size_t B = h->cfg.batch;
-  HIP_OK(hipDeviceSynchronize(), "sync");
+  HIP_OK(wait_family(h, kFamPlan), "sync");
   if (which >= 0 && which <= 2) {  // a gait matrix: stored as four 64-bit column masks, returned as N_gait x 4 doubles
     if (count > h->cfg.N_gait * 4) return fail(-1, "qrw_planner_get_host: bad item");
     double raw[4];
-    HIP_OK(hipMemcpy2D(raw, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), 4,
-                       hipMemcpyDeviceToHost), "D2H planner state");
+    HIP_OK(hipMemcpy2DAsync(raw, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), 4,
+                            hipMemcpyDeviceToHost, h->host_stream), "D2H planner state");
+    HIP_OK(host_done(h), "D2H planner state");
     for (int e = 0; e < count; e++) {
       unsigned long long mask;
       memcpy(&mask, &raw[e % 4], sizeof(mask));
@@ -1092,8 +1167,9 @@ extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int3
     return 0;
   }
   if (off < 0 || off + count > qrw::planner_state_items(h->cfg.N_gait)) return fail(-1, "qrw_planner_get_host: bad item");
-  HIP_OK(hipMemcpy2D(h_out, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), count,
-                     hipMemcpyDeviceToHost), "D2H planner state");
+  HIP_OK(hipMemcpy2DAsync(h_out, sizeof(double), h->plan_st + (size_t)off * B + b, B * sizeof(double), sizeof(double), count,
+                          hipMemcpyDeviceToHost, h->host_stream), "D2H planner state");
+  HIP_OK(host_done(h), "D2H planner state");
   return 0;
 }
 
@@ -1193,6 +1269,14 @@ extern "C" int qrw_stream_create(int32_t device, int32_t first_cu, int32_t n_cus
 }
 extern "C" int qrw_stream_destroy(void* stream) {
   if (!stream) return 0;
+  // whatever the handles launched on it is complete before the stream goes: their getters then have nothing to wait for
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  {
+    std::lock_guard<std::mutex> lock(g_handles_mutex);
+    for (qrw_handle_s* h : g_handles)
+      for (int f = 0; f < 4; f++)
+        if (h->launched[f] && h->last_stream[f] == (hipStream_t)stream) h->launched[f] = false;
+  }
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   return e == hipSuccess ? 0 : fail(-10, "qrw_stream_destroy: hipStreamDestroy failed", e);
 }
@@ -1230,5 +1314,7 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
   debug_poison_lds((hipStream_t)stream);
   if (qrw::control_pre_launch(cu, p, cw, d_x_f_mpc ? 1 : 0, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_control_pre: launch failed", hipGetLastError());
+  note_launch(h, kFamPlan, (hipStream_t)stream);
+  note_launch(h, kFamCtrl, (hipStream_t)stream);
   return 0;
 }

@@ -96,7 +96,6 @@ int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
 int mpc_pre_error_flush(const unsigned* pre_ctr, unsigned* host_word, hipStream_t stream);  // error word -> host-mapped word, if set
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);
-bool mpc_build_is_timing_experiment();
 constexpr int kSeqErrWord = 4 * 16;              // kSeqLevels * kSeqStride: the error flag's word in qctr (mpc_kernel.hip)
 constexpr int kSeqQctrWords = kSeqErrWord + 32;  // + error / diagnostics / level totals / level bases
 int mpc_sequence_launch(const MpcArgs& a, hipStream_t stream);

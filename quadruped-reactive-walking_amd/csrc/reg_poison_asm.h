@@ -1,517 +1,22 @@
-// GENERATED (scripts: inline): the body of reg_poison_kernel -- every architectural and accumulation vector register of the wavefront
-// set to all-ones (a NaN in either half of a double).  Diagnostic only (QRW_DEBUG_POISON_LDS / qrw_test_known_answer).
-#define QRW_REG_POISON_ASM \
-  "v_mov_b32 v0, -1\n\t" \
-  "v_mov_b32 v1, -1\n\t" \
-  "v_mov_b32 v2, -1\n\t" \
-  "v_mov_b32 v3, -1\n\t" \
-  "v_mov_b32 v4, -1\n\t" \
-  "v_mov_b32 v5, -1\n\t" \
-  "v_mov_b32 v6, -1\n\t" \
-  "v_mov_b32 v7, -1\n\t" \
-  "v_mov_b32 v8, -1\n\t" \
-  "v_mov_b32 v9, -1\n\t" \
-  "v_mov_b32 v10, -1\n\t" \
-  "v_mov_b32 v11, -1\n\t" \
-  "v_mov_b32 v12, -1\n\t" \
-  "v_mov_b32 v13, -1\n\t" \
-  "v_mov_b32 v14, -1\n\t" \
-  "v_mov_b32 v15, -1\n\t" \
-  "v_mov_b32 v16, -1\n\t" \
-  "v_mov_b32 v17, -1\n\t" \
-  "v_mov_b32 v18, -1\n\t" \
-  "v_mov_b32 v19, -1\n\t" \
-  "v_mov_b32 v20, -1\n\t" \
-  "v_mov_b32 v21, -1\n\t" \
-  "v_mov_b32 v22, -1\n\t" \
-  "v_mov_b32 v23, -1\n\t" \
-  "v_mov_b32 v24, -1\n\t" \
-  "v_mov_b32 v25, -1\n\t" \
-  "v_mov_b32 v26, -1\n\t" \
-  "v_mov_b32 v27, -1\n\t" \
-  "v_mov_b32 v28, -1\n\t" \
-  "v_mov_b32 v29, -1\n\t" \
-  "v_mov_b32 v30, -1\n\t" \
-  "v_mov_b32 v31, -1\n\t" \
-  "v_mov_b32 v32, -1\n\t" \
-  "v_mov_b32 v33, -1\n\t" \
-  "v_mov_b32 v34, -1\n\t" \
-  "v_mov_b32 v35, -1\n\t" \
-  "v_mov_b32 v36, -1\n\t" \
-  "v_mov_b32 v37, -1\n\t" \
-  "v_mov_b32 v38, -1\n\t" \
-  "v_mov_b32 v39, -1\n\t" \
-  "v_mov_b32 v40, -1\n\t" \
-  "v_mov_b32 v41, -1\n\t" \
-  "v_mov_b32 v42, -1\n\t" \
-  "v_mov_b32 v43, -1\n\t" \
-  "v_mov_b32 v44, -1\n\t" \
-  "v_mov_b32 v45, -1\n\t" \
-  "v_mov_b32 v46, -1\n\t" \
-  "v_mov_b32 v47, -1\n\t" \
-  "v_mov_b32 v48, -1\n\t" \
-  "v_mov_b32 v49, -1\n\t" \
-  "v_mov_b32 v50, -1\n\t" \
-  "v_mov_b32 v51, -1\n\t" \
-  "v_mov_b32 v52, -1\n\t" \
-  "v_mov_b32 v53, -1\n\t" \
-  "v_mov_b32 v54, -1\n\t" \
-  "v_mov_b32 v55, -1\n\t" \
-  "v_mov_b32 v56, -1\n\t" \
-  "v_mov_b32 v57, -1\n\t" \
-  "v_mov_b32 v58, -1\n\t" \
-  "v_mov_b32 v59, -1\n\t" \
-  "v_mov_b32 v60, -1\n\t" \
-  "v_mov_b32 v61, -1\n\t" \
-  "v_mov_b32 v62, -1\n\t" \
-  "v_mov_b32 v63, -1\n\t" \
-  "v_mov_b32 v64, -1\n\t" \
-  "v_mov_b32 v65, -1\n\t" \
-  "v_mov_b32 v66, -1\n\t" \
-  "v_mov_b32 v67, -1\n\t" \
-  "v_mov_b32 v68, -1\n\t" \
-  "v_mov_b32 v69, -1\n\t" \
-  "v_mov_b32 v70, -1\n\t" \
-  "v_mov_b32 v71, -1\n\t" \
-  "v_mov_b32 v72, -1\n\t" \
-  "v_mov_b32 v73, -1\n\t" \
-  "v_mov_b32 v74, -1\n\t" \
-  "v_mov_b32 v75, -1\n\t" \
-  "v_mov_b32 v76, -1\n\t" \
-  "v_mov_b32 v77, -1\n\t" \
-  "v_mov_b32 v78, -1\n\t" \
-  "v_mov_b32 v79, -1\n\t" \
-  "v_mov_b32 v80, -1\n\t" \
-  "v_mov_b32 v81, -1\n\t" \
-  "v_mov_b32 v82, -1\n\t" \
-  "v_mov_b32 v83, -1\n\t" \
-  "v_mov_b32 v84, -1\n\t" \
-  "v_mov_b32 v85, -1\n\t" \
-  "v_mov_b32 v86, -1\n\t" \
-  "v_mov_b32 v87, -1\n\t" \
-  "v_mov_b32 v88, -1\n\t" \
-  "v_mov_b32 v89, -1\n\t" \
-  "v_mov_b32 v90, -1\n\t" \
-  "v_mov_b32 v91, -1\n\t" \
-  "v_mov_b32 v92, -1\n\t" \
-  "v_mov_b32 v93, -1\n\t" \
-  "v_mov_b32 v94, -1\n\t" \
-  "v_mov_b32 v95, -1\n\t" \
-  "v_mov_b32 v96, -1\n\t" \
-  "v_mov_b32 v97, -1\n\t" \
-  "v_mov_b32 v98, -1\n\t" \
-  "v_mov_b32 v99, -1\n\t" \
-  "v_mov_b32 v100, -1\n\t" \
-  "v_mov_b32 v101, -1\n\t" \
-  "v_mov_b32 v102, -1\n\t" \
-  "v_mov_b32 v103, -1\n\t" \
-  "v_mov_b32 v104, -1\n\t" \
-  "v_mov_b32 v105, -1\n\t" \
-  "v_mov_b32 v106, -1\n\t" \
-  "v_mov_b32 v107, -1\n\t" \
-  "v_mov_b32 v108, -1\n\t" \
-  "v_mov_b32 v109, -1\n\t" \
-  "v_mov_b32 v110, -1\n\t" \
-  "v_mov_b32 v111, -1\n\t" \
-  "v_mov_b32 v112, -1\n\t" \
-  "v_mov_b32 v113, -1\n\t" \
-  "v_mov_b32 v114, -1\n\t" \
-  "v_mov_b32 v115, -1\n\t" \
-  "v_mov_b32 v116, -1\n\t" \
-  "v_mov_b32 v117, -1\n\t" \
-  "v_mov_b32 v118, -1\n\t" \
-  "v_mov_b32 v119, -1\n\t" \
-  "v_mov_b32 v120, -1\n\t" \
-  "v_mov_b32 v121, -1\n\t" \
-  "v_mov_b32 v122, -1\n\t" \
-  "v_mov_b32 v123, -1\n\t" \
-  "v_mov_b32 v124, -1\n\t" \
-  "v_mov_b32 v125, -1\n\t" \
-  "v_mov_b32 v126, -1\n\t" \
-  "v_mov_b32 v127, -1\n\t" \
-  "v_mov_b32 v128, -1\n\t" \
-  "v_mov_b32 v129, -1\n\t" \
-  "v_mov_b32 v130, -1\n\t" \
-  "v_mov_b32 v131, -1\n\t" \
-  "v_mov_b32 v132, -1\n\t" \
-  "v_mov_b32 v133, -1\n\t" \
-  "v_mov_b32 v134, -1\n\t" \
-  "v_mov_b32 v135, -1\n\t" \
-  "v_mov_b32 v136, -1\n\t" \
-  "v_mov_b32 v137, -1\n\t" \
-  "v_mov_b32 v138, -1\n\t" \
-  "v_mov_b32 v139, -1\n\t" \
-  "v_mov_b32 v140, -1\n\t" \
-  "v_mov_b32 v141, -1\n\t" \
-  "v_mov_b32 v142, -1\n\t" \
-  "v_mov_b32 v143, -1\n\t" \
-  "v_mov_b32 v144, -1\n\t" \
-  "v_mov_b32 v145, -1\n\t" \
-  "v_mov_b32 v146, -1\n\t" \
-  "v_mov_b32 v147, -1\n\t" \
-  "v_mov_b32 v148, -1\n\t" \
-  "v_mov_b32 v149, -1\n\t" \
-  "v_mov_b32 v150, -1\n\t" \
-  "v_mov_b32 v151, -1\n\t" \
-  "v_mov_b32 v152, -1\n\t" \
-  "v_mov_b32 v153, -1\n\t" \
-  "v_mov_b32 v154, -1\n\t" \
-  "v_mov_b32 v155, -1\n\t" \
-  "v_mov_b32 v156, -1\n\t" \
-  "v_mov_b32 v157, -1\n\t" \
-  "v_mov_b32 v158, -1\n\t" \
-  "v_mov_b32 v159, -1\n\t" \
-  "v_mov_b32 v160, -1\n\t" \
-  "v_mov_b32 v161, -1\n\t" \
-  "v_mov_b32 v162, -1\n\t" \
-  "v_mov_b32 v163, -1\n\t" \
-  "v_mov_b32 v164, -1\n\t" \
-  "v_mov_b32 v165, -1\n\t" \
-  "v_mov_b32 v166, -1\n\t" \
-  "v_mov_b32 v167, -1\n\t" \
-  "v_mov_b32 v168, -1\n\t" \
-  "v_mov_b32 v169, -1\n\t" \
-  "v_mov_b32 v170, -1\n\t" \
-  "v_mov_b32 v171, -1\n\t" \
-  "v_mov_b32 v172, -1\n\t" \
-  "v_mov_b32 v173, -1\n\t" \
-  "v_mov_b32 v174, -1\n\t" \
-  "v_mov_b32 v175, -1\n\t" \
-  "v_mov_b32 v176, -1\n\t" \
-  "v_mov_b32 v177, -1\n\t" \
-  "v_mov_b32 v178, -1\n\t" \
-  "v_mov_b32 v179, -1\n\t" \
-  "v_mov_b32 v180, -1\n\t" \
-  "v_mov_b32 v181, -1\n\t" \
-  "v_mov_b32 v182, -1\n\t" \
-  "v_mov_b32 v183, -1\n\t" \
-  "v_mov_b32 v184, -1\n\t" \
-  "v_mov_b32 v185, -1\n\t" \
-  "v_mov_b32 v186, -1\n\t" \
-  "v_mov_b32 v187, -1\n\t" \
-  "v_mov_b32 v188, -1\n\t" \
-  "v_mov_b32 v189, -1\n\t" \
-  "v_mov_b32 v190, -1\n\t" \
-  "v_mov_b32 v191, -1\n\t" \
-  "v_mov_b32 v192, -1\n\t" \
-  "v_mov_b32 v193, -1\n\t" \
-  "v_mov_b32 v194, -1\n\t" \
-  "v_mov_b32 v195, -1\n\t" \
-  "v_mov_b32 v196, -1\n\t" \
-  "v_mov_b32 v197, -1\n\t" \
-  "v_mov_b32 v198, -1\n\t" \
-  "v_mov_b32 v199, -1\n\t" \
-  "v_mov_b32 v200, -1\n\t" \
-  "v_mov_b32 v201, -1\n\t" \
-  "v_mov_b32 v202, -1\n\t" \
-  "v_mov_b32 v203, -1\n\t" \
-  "v_mov_b32 v204, -1\n\t" \
-  "v_mov_b32 v205, -1\n\t" \
-  "v_mov_b32 v206, -1\n\t" \
-  "v_mov_b32 v207, -1\n\t" \
-  "v_mov_b32 v208, -1\n\t" \
-  "v_mov_b32 v209, -1\n\t" \
-  "v_mov_b32 v210, -1\n\t" \
-  "v_mov_b32 v211, -1\n\t" \
-  "v_mov_b32 v212, -1\n\t" \
-  "v_mov_b32 v213, -1\n\t" \
-  "v_mov_b32 v214, -1\n\t" \
-  "v_mov_b32 v215, -1\n\t" \
-  "v_mov_b32 v216, -1\n\t" \
-  "v_mov_b32 v217, -1\n\t" \
-  "v_mov_b32 v218, -1\n\t" \
-  "v_mov_b32 v219, -1\n\t" \
-  "v_mov_b32 v220, -1\n\t" \
-  "v_mov_b32 v221, -1\n\t" \
-  "v_mov_b32 v222, -1\n\t" \
-  "v_mov_b32 v223, -1\n\t" \
-  "v_mov_b32 v224, -1\n\t" \
-  "v_mov_b32 v225, -1\n\t" \
-  "v_mov_b32 v226, -1\n\t" \
-  "v_mov_b32 v227, -1\n\t" \
-  "v_mov_b32 v228, -1\n\t" \
-  "v_mov_b32 v229, -1\n\t" \
-  "v_mov_b32 v230, -1\n\t" \
-  "v_mov_b32 v231, -1\n\t" \
-  "v_mov_b32 v232, -1\n\t" \
-  "v_mov_b32 v233, -1\n\t" \
-  "v_mov_b32 v234, -1\n\t" \
-  "v_mov_b32 v235, -1\n\t" \
-  "v_mov_b32 v236, -1\n\t" \
-  "v_mov_b32 v237, -1\n\t" \
-  "v_mov_b32 v238, -1\n\t" \
-  "v_mov_b32 v239, -1\n\t" \
-  "v_mov_b32 v240, -1\n\t" \
-  "v_mov_b32 v241, -1\n\t" \
-  "v_mov_b32 v242, -1\n\t" \
-  "v_mov_b32 v243, -1\n\t" \
-  "v_mov_b32 v244, -1\n\t" \
-  "v_mov_b32 v245, -1\n\t" \
-  "v_mov_b32 v246, -1\n\t" \
-  "v_mov_b32 v247, -1\n\t" \
-  "v_mov_b32 v248, -1\n\t" \
-  "v_mov_b32 v249, -1\n\t" \
-  "v_mov_b32 v250, -1\n\t" \
-  "v_mov_b32 v251, -1\n\t" \
-  "v_mov_b32 v252, -1\n\t" \
-  "v_mov_b32 v253, -1\n\t" \
-  "v_mov_b32 v254, -1\n\t" \
-  "v_mov_b32 v255, -1\n\t" \
-  "v_accvgpr_write_b32 a0, v0\n\t" \
-  "v_accvgpr_write_b32 a1, v0\n\t" \
-  "v_accvgpr_write_b32 a2, v0\n\t" \
-  "v_accvgpr_write_b32 a3, v0\n\t" \
-  "v_accvgpr_write_b32 a4, v0\n\t" \
-  "v_accvgpr_write_b32 a5, v0\n\t" \
-  "v_accvgpr_write_b32 a6, v0\n\t" \
-  "v_accvgpr_write_b32 a7, v0\n\t" \
-  "v_accvgpr_write_b32 a8, v0\n\t" \
-  "v_accvgpr_write_b32 a9, v0\n\t" \
-  "v_accvgpr_write_b32 a10, v0\n\t" \
-  "v_accvgpr_write_b32 a11, v0\n\t" \
-  "v_accvgpr_write_b32 a12, v0\n\t" \
-  "v_accvgpr_write_b32 a13, v0\n\t" \
-  "v_accvgpr_write_b32 a14, v0\n\t" \
-  "v_accvgpr_write_b32 a15, v0\n\t" \
-  "v_accvgpr_write_b32 a16, v0\n\t" \
-  "v_accvgpr_write_b32 a17, v0\n\t" \
-  "v_accvgpr_write_b32 a18, v0\n\t" \
-  "v_accvgpr_write_b32 a19, v0\n\t" \
-  "v_accvgpr_write_b32 a20, v0\n\t" \
-  "v_accvgpr_write_b32 a21, v0\n\t" \
-  "v_accvgpr_write_b32 a22, v0\n\t" \
-  "v_accvgpr_write_b32 a23, v0\n\t" \
-  "v_accvgpr_write_b32 a24, v0\n\t" \
-  "v_accvgpr_write_b32 a25, v0\n\t" \
-  "v_accvgpr_write_b32 a26, v0\n\t" \
-  "v_accvgpr_write_b32 a27, v0\n\t" \
-  "v_accvgpr_write_b32 a28, v0\n\t" \
-  "v_accvgpr_write_b32 a29, v0\n\t" \
-  "v_accvgpr_write_b32 a30, v0\n\t" \
-  "v_accvgpr_write_b32 a31, v0\n\t" \
-  "v_accvgpr_write_b32 a32, v0\n\t" \
-  "v_accvgpr_write_b32 a33, v0\n\t" \
-  "v_accvgpr_write_b32 a34, v0\n\t" \
-  "v_accvgpr_write_b32 a35, v0\n\t" \
-  "v_accvgpr_write_b32 a36, v0\n\t" \
-  "v_accvgpr_write_b32 a37, v0\n\t" \
-  "v_accvgpr_write_b32 a38, v0\n\t" \
-  "v_accvgpr_write_b32 a39, v0\n\t" \
-  "v_accvgpr_write_b32 a40, v0\n\t" \
-  "v_accvgpr_write_b32 a41, v0\n\t" \
-  "v_accvgpr_write_b32 a42, v0\n\t" \
-  "v_accvgpr_write_b32 a43, v0\n\t" \
-  "v_accvgpr_write_b32 a44, v0\n\t" \
-  "v_accvgpr_write_b32 a45, v0\n\t" \
-  "v_accvgpr_write_b32 a46, v0\n\t" \
-  "v_accvgpr_write_b32 a47, v0\n\t" \
-  "v_accvgpr_write_b32 a48, v0\n\t" \
-  "v_accvgpr_write_b32 a49, v0\n\t" \
-  "v_accvgpr_write_b32 a50, v0\n\t" \
-  "v_accvgpr_write_b32 a51, v0\n\t" \
-  "v_accvgpr_write_b32 a52, v0\n\t" \
-  "v_accvgpr_write_b32 a53, v0\n\t" \
-  "v_accvgpr_write_b32 a54, v0\n\t" \
-  "v_accvgpr_write_b32 a55, v0\n\t" \
-  "v_accvgpr_write_b32 a56, v0\n\t" \
-  "v_accvgpr_write_b32 a57, v0\n\t" \
-  "v_accvgpr_write_b32 a58, v0\n\t" \
-  "v_accvgpr_write_b32 a59, v0\n\t" \
-  "v_accvgpr_write_b32 a60, v0\n\t" \
-  "v_accvgpr_write_b32 a61, v0\n\t" \
-  "v_accvgpr_write_b32 a62, v0\n\t" \
-  "v_accvgpr_write_b32 a63, v0\n\t" \
-  "v_accvgpr_write_b32 a64, v0\n\t" \
-  "v_accvgpr_write_b32 a65, v0\n\t" \
-  "v_accvgpr_write_b32 a66, v0\n\t" \
-  "v_accvgpr_write_b32 a67, v0\n\t" \
-  "v_accvgpr_write_b32 a68, v0\n\t" \
-  "v_accvgpr_write_b32 a69, v0\n\t" \
-  "v_accvgpr_write_b32 a70, v0\n\t" \
-  "v_accvgpr_write_b32 a71, v0\n\t" \
-  "v_accvgpr_write_b32 a72, v0\n\t" \
-  "v_accvgpr_write_b32 a73, v0\n\t" \
-  "v_accvgpr_write_b32 a74, v0\n\t" \
-  "v_accvgpr_write_b32 a75, v0\n\t" \
-  "v_accvgpr_write_b32 a76, v0\n\t" \
-  "v_accvgpr_write_b32 a77, v0\n\t" \
-  "v_accvgpr_write_b32 a78, v0\n\t" \
-  "v_accvgpr_write_b32 a79, v0\n\t" \
-  "v_accvgpr_write_b32 a80, v0\n\t" \
-  "v_accvgpr_write_b32 a81, v0\n\t" \
-  "v_accvgpr_write_b32 a82, v0\n\t" \
-  "v_accvgpr_write_b32 a83, v0\n\t" \
-  "v_accvgpr_write_b32 a84, v0\n\t" \
-  "v_accvgpr_write_b32 a85, v0\n\t" \
-  "v_accvgpr_write_b32 a86, v0\n\t" \
-  "v_accvgpr_write_b32 a87, v0\n\t" \
-  "v_accvgpr_write_b32 a88, v0\n\t" \
-  "v_accvgpr_write_b32 a89, v0\n\t" \
-  "v_accvgpr_write_b32 a90, v0\n\t" \
-  "v_accvgpr_write_b32 a91, v0\n\t" \
-  "v_accvgpr_write_b32 a92, v0\n\t" \
-  "v_accvgpr_write_b32 a93, v0\n\t" \
-  "v_accvgpr_write_b32 a94, v0\n\t" \
-  "v_accvgpr_write_b32 a95, v0\n\t" \
-  "v_accvgpr_write_b32 a96, v0\n\t" \
-  "v_accvgpr_write_b32 a97, v0\n\t" \
-  "v_accvgpr_write_b32 a98, v0\n\t" \
-  "v_accvgpr_write_b32 a99, v0\n\t" \
-  "v_accvgpr_write_b32 a100, v0\n\t" \
-  "v_accvgpr_write_b32 a101, v0\n\t" \
-  "v_accvgpr_write_b32 a102, v0\n\t" \
-  "v_accvgpr_write_b32 a103, v0\n\t" \
-  "v_accvgpr_write_b32 a104, v0\n\t" \
-  "v_accvgpr_write_b32 a105, v0\n\t" \
-  "v_accvgpr_write_b32 a106, v0\n\t" \
-  "v_accvgpr_write_b32 a107, v0\n\t" \
-  "v_accvgpr_write_b32 a108, v0\n\t" \
-  "v_accvgpr_write_b32 a109, v0\n\t" \
-  "v_accvgpr_write_b32 a110, v0\n\t" \
-  "v_accvgpr_write_b32 a111, v0\n\t" \
-  "v_accvgpr_write_b32 a112, v0\n\t" \
-  "v_accvgpr_write_b32 a113, v0\n\t" \
-  "v_accvgpr_write_b32 a114, v0\n\t" \
-  "v_accvgpr_write_b32 a115, v0\n\t" \
-  "v_accvgpr_write_b32 a116, v0\n\t" \
-  "v_accvgpr_write_b32 a117, v0\n\t" \
-  "v_accvgpr_write_b32 a118, v0\n\t" \
-  "v_accvgpr_write_b32 a119, v0\n\t" \
-  "v_accvgpr_write_b32 a120, v0\n\t" \
-  "v_accvgpr_write_b32 a121, v0\n\t" \
-  "v_accvgpr_write_b32 a122, v0\n\t" \
-  "v_accvgpr_write_b32 a123, v0\n\t" \
-  "v_accvgpr_write_b32 a124, v0\n\t" \
-  "v_accvgpr_write_b32 a125, v0\n\t" \
-  "v_accvgpr_write_b32 a126, v0\n\t" \
-  "v_accvgpr_write_b32 a127, v0\n\t" \
-  "v_accvgpr_write_b32 a128, v0\n\t" \
-  "v_accvgpr_write_b32 a129, v0\n\t" \
-  "v_accvgpr_write_b32 a130, v0\n\t" \
-  "v_accvgpr_write_b32 a131, v0\n\t" \
-  "v_accvgpr_write_b32 a132, v0\n\t" \
-  "v_accvgpr_write_b32 a133, v0\n\t" \
-  "v_accvgpr_write_b32 a134, v0\n\t" \
-  "v_accvgpr_write_b32 a135, v0\n\t" \
-  "v_accvgpr_write_b32 a136, v0\n\t" \
-  "v_accvgpr_write_b32 a137, v0\n\t" \
-  "v_accvgpr_write_b32 a138, v0\n\t" \
-  "v_accvgpr_write_b32 a139, v0\n\t" \
-  "v_accvgpr_write_b32 a140, v0\n\t" \
-  "v_accvgpr_write_b32 a141, v0\n\t" \
-  "v_accvgpr_write_b32 a142, v0\n\t" \
-  "v_accvgpr_write_b32 a143, v0\n\t" \
-  "v_accvgpr_write_b32 a144, v0\n\t" \
-  "v_accvgpr_write_b32 a145, v0\n\t" \
-  "v_accvgpr_write_b32 a146, v0\n\t" \
-  "v_accvgpr_write_b32 a147, v0\n\t" \
-  "v_accvgpr_write_b32 a148, v0\n\t" \
-  "v_accvgpr_write_b32 a149, v0\n\t" \
-  "v_accvgpr_write_b32 a150, v0\n\t" \
-  "v_accvgpr_write_b32 a151, v0\n\t" \
-  "v_accvgpr_write_b32 a152, v0\n\t" \
-  "v_accvgpr_write_b32 a153, v0\n\t" \
-  "v_accvgpr_write_b32 a154, v0\n\t" \
-  "v_accvgpr_write_b32 a155, v0\n\t" \
-  "v_accvgpr_write_b32 a156, v0\n\t" \
-  "v_accvgpr_write_b32 a157, v0\n\t" \
-  "v_accvgpr_write_b32 a158, v0\n\t" \
-  "v_accvgpr_write_b32 a159, v0\n\t" \
-  "v_accvgpr_write_b32 a160, v0\n\t" \
-  "v_accvgpr_write_b32 a161, v0\n\t" \
-  "v_accvgpr_write_b32 a162, v0\n\t" \
-  "v_accvgpr_write_b32 a163, v0\n\t" \
-  "v_accvgpr_write_b32 a164, v0\n\t" \
-  "v_accvgpr_write_b32 a165, v0\n\t" \
-  "v_accvgpr_write_b32 a166, v0\n\t" \
-  "v_accvgpr_write_b32 a167, v0\n\t" \
-  "v_accvgpr_write_b32 a168, v0\n\t" \
-  "v_accvgpr_write_b32 a169, v0\n\t" \
-  "v_accvgpr_write_b32 a170, v0\n\t" \
-  "v_accvgpr_write_b32 a171, v0\n\t" \
-  "v_accvgpr_write_b32 a172, v0\n\t" \
-  "v_accvgpr_write_b32 a173, v0\n\t" \
-  "v_accvgpr_write_b32 a174, v0\n\t" \
-  "v_accvgpr_write_b32 a175, v0\n\t" \
-  "v_accvgpr_write_b32 a176, v0\n\t" \
-  "v_accvgpr_write_b32 a177, v0\n\t" \
-  "v_accvgpr_write_b32 a178, v0\n\t" \
-  "v_accvgpr_write_b32 a179, v0\n\t" \
-  "v_accvgpr_write_b32 a180, v0\n\t" \
-  "v_accvgpr_write_b32 a181, v0\n\t" \
-  "v_accvgpr_write_b32 a182, v0\n\t" \
-  "v_accvgpr_write_b32 a183, v0\n\t" \
-  "v_accvgpr_write_b32 a184, v0\n\t" \
-  "v_accvgpr_write_b32 a185, v0\n\t" \
-  "v_accvgpr_write_b32 a186, v0\n\t" \
-  "v_accvgpr_write_b32 a187, v0\n\t" \
-  "v_accvgpr_write_b32 a188, v0\n\t" \
-  "v_accvgpr_write_b32 a189, v0\n\t" \
-  "v_accvgpr_write_b32 a190, v0\n\t" \
-  "v_accvgpr_write_b32 a191, v0\n\t" \
-  "v_accvgpr_write_b32 a192, v0\n\t" \
-  "v_accvgpr_write_b32 a193, v0\n\t" \
-  "v_accvgpr_write_b32 a194, v0\n\t" \
-  "v_accvgpr_write_b32 a195, v0\n\t" \
-  "v_accvgpr_write_b32 a196, v0\n\t" \
-  "v_accvgpr_write_b32 a197, v0\n\t" \
-  "v_accvgpr_write_b32 a198, v0\n\t" \
-  "v_accvgpr_write_b32 a199, v0\n\t" \
-  "v_accvgpr_write_b32 a200, v0\n\t" \
-  "v_accvgpr_write_b32 a201, v0\n\t" \
-  "v_accvgpr_write_b32 a202, v0\n\t" \
-  "v_accvgpr_write_b32 a203, v0\n\t" \
-  "v_accvgpr_write_b32 a204, v0\n\t" \
-  "v_accvgpr_write_b32 a205, v0\n\t" \
-  "v_accvgpr_write_b32 a206, v0\n\t" \
-  "v_accvgpr_write_b32 a207, v0\n\t" \
-  "v_accvgpr_write_b32 a208, v0\n\t" \
-  "v_accvgpr_write_b32 a209, v0\n\t" \
-  "v_accvgpr_write_b32 a210, v0\n\t" \
-  "v_accvgpr_write_b32 a211, v0\n\t" \
-  "v_accvgpr_write_b32 a212, v0\n\t" \
-  "v_accvgpr_write_b32 a213, v0\n\t" \
-  "v_accvgpr_write_b32 a214, v0\n\t" \
-  "v_accvgpr_write_b32 a215, v0\n\t" \
-  "v_accvgpr_write_b32 a216, v0\n\t" \
-  "v_accvgpr_write_b32 a217, v0\n\t" \
-  "v_accvgpr_write_b32 a218, v0\n\t" \
-  "v_accvgpr_write_b32 a219, v0\n\t" \
-  "v_accvgpr_write_b32 a220, v0\n\t" \
-  "v_accvgpr_write_b32 a221, v0\n\t" \
-  "v_accvgpr_write_b32 a222, v0\n\t" \
-  "v_accvgpr_write_b32 a223, v0\n\t" \
-  "v_accvgpr_write_b32 a224, v0\n\t" \
-  "v_accvgpr_write_b32 a225, v0\n\t" \
-  "v_accvgpr_write_b32 a226, v0\n\t" \
-  "v_accvgpr_write_b32 a227, v0\n\t" \
-  "v_accvgpr_write_b32 a228, v0\n\t" \
-  "v_accvgpr_write_b32 a229, v0\n\t" \
-  "v_accvgpr_write_b32 a230, v0\n\t" \
-  "v_accvgpr_write_b32 a231, v0\n\t" \
-  "v_accvgpr_write_b32 a232, v0\n\t" \
-  "v_accvgpr_write_b32 a233, v0\n\t" \
-  "v_accvgpr_write_b32 a234, v0\n\t" \
-  "v_accvgpr_write_b32 a235, v0\n\t" \
-  "v_accvgpr_write_b32 a236, v0\n\t" \
-  "v_accvgpr_write_b32 a237, v0\n\t" \
-  "v_accvgpr_write_b32 a238, v0\n\t" \
-  "v_accvgpr_write_b32 a239, v0\n\t" \
-  "v_accvgpr_write_b32 a240, v0\n\t" \
-  "v_accvgpr_write_b32 a241, v0\n\t" \
-  "v_accvgpr_write_b32 a242, v0\n\t" \
-  "v_accvgpr_write_b32 a243, v0\n\t" \
-  "v_accvgpr_write_b32 a244, v0\n\t" \
-  "v_accvgpr_write_b32 a245, v0\n\t" \
-  "v_accvgpr_write_b32 a246, v0\n\t" \
-  "v_accvgpr_write_b32 a247, v0\n\t" \
-  "v_accvgpr_write_b32 a248, v0\n\t" \
-  "v_accvgpr_write_b32 a249, v0\n\t" \
-  "v_accvgpr_write_b32 a250, v0\n\t" \
-  "v_accvgpr_write_b32 a251, v0\n\t" \
-  "v_accvgpr_write_b32 a252, v0\n\t" \
-  "v_accvgpr_write_b32 a253, v0\n\t" \
-  "v_accvgpr_write_b32 a254, v0\n\t" \
-  "v_accvgpr_write_b32 a255, v0\n\t" \
+// The body of reg_poison_kernel: every architectural and accumulation vector register of the wavefront set to all-ones (a NaN in
+// either half of a double), as an assembler loop.  Diagnostic only (QRW_DEBUG_POISON_LDS / qrw_test_known_answer).
+#define QRW_REG_POISON_ASM            \
+  ".set qrw_poison_i, 0\n\t"          \
+  ".rept 256\n\t"                     \
+  "v_mov_b32 v[qrw_poison_i], -1\n\t" \
+  ".set qrw_poison_i, qrw_poison_i + 1\n\t" \
+  ".endr\n\t"                         \
+  ".set qrw_poison_i, 0\n\t"          \
+  ".rept 256\n\t"                     \
+  "v_accvgpr_write_b32 a[qrw_poison_i], v0\n\t" \
+  ".set qrw_poison_i, qrw_poison_i + 1\n\t" \
+  ".endr\n\t"                         \
   "s_nop 0"
-#define QRW_REG_POISON_CLOBBERS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+// the clobber list (all 512 registers: it is what makes the compiler give the kernel the whole register file)
+#define QRW_R10(p, t) p #t "0", p #t "1", p #t "2", p #t "3", p #t "4", p #t "5", p #t "6", p #t "7", p #t "8", p #t "9"
+#define QRW_R256(p)                                                                                                              \
+  QRW_R10(p, ), QRW_R10(p, 1), QRW_R10(p, 2), QRW_R10(p, 3), QRW_R10(p, 4), QRW_R10(p, 5), QRW_R10(p, 6), QRW_R10(p, 7),         \
+  QRW_R10(p, 8), QRW_R10(p, 9), QRW_R10(p, 10), QRW_R10(p, 11), QRW_R10(p, 12), QRW_R10(p, 13), QRW_R10(p, 14), QRW_R10(p, 15),  \
+  QRW_R10(p, 16), QRW_R10(p, 17), QRW_R10(p, 18), QRW_R10(p, 19), QRW_R10(p, 20), QRW_R10(p, 21), QRW_R10(p, 22),                \
+  QRW_R10(p, 23), QRW_R10(p, 24), p "250", p "251", p "252", p "253", p "254", p "255"
+#define QRW_REG_POISON_CLOBBERS QRW_R256("v"), QRW_R256("a")

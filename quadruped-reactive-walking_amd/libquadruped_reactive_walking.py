@@ -23,8 +23,9 @@ class MPC:
     def __init__(self, dt_in=None, n_steps_in=None, T_gait_in=None, N_gait=None):
         if dt_in is None:
             raise NotImplementedError("default-constructed MPC (src/MPC.cpp:34) has no parameters to run with")
-        self._b = qrw_hip.Batch(1, n_steps=int(n_steps_in), N_gait=int(N_gait), dt_mpc=float(dt_in),
-                                T_gait=float(T_gait_in))
+        # the process-wide batch-1 handle of this configuration (its MPC state, if no other MPC object has it yet)
+        self._b = qrw_hip.shared_batch1("mpc", n_steps=int(n_steps_in), N_gait=int(N_gait), dt_mpc=float(dt_in),
+                                        T_gait=float(T_gait_in))
         self._res = np.zeros((24, int(n_steps_in)))  # x_f_applied starts at zero (src/MPC.cpp:12)
 
     def run(self, num_iter, xref_in, fsteps_in):
@@ -51,7 +52,7 @@ class InvKin:
     """InvKin(dt_in) — python/gepadd.cpp:186-195, src/InvKin.cpp."""
 
     def __init__(self, dt_in=0.0):
-        self._b = qrw_hip.Batch(1, dt_wbc=float(dt_in) if dt_in else 0.002)
+        self._b = qrw_hip.shared_batch1("stateless", dt_wbc=float(dt_in) if dt_in else 0.002)
         self._q_step = np.zeros(12)
         self._dq_cmd = np.zeros(12)
 
@@ -75,7 +76,7 @@ class QPWBC:
     """QPWBC() — python/gepadd.cpp:217-224, src/QPWBC.cpp."""
 
     def __init__(self):
-        self._b = qrw_hip.Batch(1)
+        self._b = qrw_hip.shared_batch1("wbc")
         self._f_res = np.zeros(12)
         self._ddq_res = np.zeros(12)  # src/QPWBC.hpp:47 (12x1 until the first run resizes it to 6x1)
         self._H = np.zeros((12, 12))

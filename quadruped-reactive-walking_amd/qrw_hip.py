@@ -52,10 +52,6 @@ SIGNATURES = {
     "qrw_mpc_get_stats": (C.c_int, [_vp, _ip, _ip, _dp, _dp, _dp]),
     "qrw_mpc_get_state": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "qrw_mpc_get_order": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "qrw_test_poke_aborted": (C.c_int, [_vp, C.c_int32]),
-    "qrw_test_poison_probe": (C.c_int, [C.POINTER(C.c_uint32)]),
-    "qrw_test_known_answer": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qrw_mpc_get_slice_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "qrw_wbc_compute": (C.c_int, [_vp] + [_vp] * 13 + [_vp]),
     "qrw_wbc_compute_host": (C.c_int, [_vp] + [_dp] * 13),
@@ -85,6 +81,14 @@ SIGNATURES = {
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
 
+# test-suite-only entry points (include/qrw_hip_test.h): fault injection and LDS / register poisoning
+TEST_SIGNATURES = {
+    "qrw_test_poke_aborted": (C.c_int, [_vp, C.c_int32]),
+    "qrw_test_poison_probe": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "qrw_test_known_answer": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
 _lib = None
 
 
@@ -103,8 +107,11 @@ def load_library():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the host API
         pass
+    if os.path.basename(_LIB_PATH).startswith("WRONG_RESULTS") and os.environ.get("QRW_ALLOW_WRONG_RESULTS") != "1":
+        raise QrwError("%s is a timing-experiment build that computes wrong results on purpose (scripts/experiments/); "
+                       "set QRW_ALLOW_WRONG_RESULTS=1 to load it for a timing run" % _LIB_PATH)
     lib = C.CDLL(_LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -620,6 +627,37 @@ class Batch:
 
     def state_bytes(self):
         return int(self._lib.qrw_state_bytes(self._handle))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One process-wide batch-1 handle for the single-robot drop-in classes (libquadruped_reactive_walking.MPC / QPWBC / InvKin,
+# QP_WBC.wbc_controller, solo12InvKin.Solo12InvKin): the reference's Controller builds one object of each, and giving every
+# object its own handle meant five qrw_create calls (25 allocations each) for one robot.  A handle holds one set of persistent
+# state per family -- "mpc" (warm start, rho, stale B / S entries), "wbc" (the box-QP's iterates) -- so the first object that
+# needs a family's state on a given configuration takes it from the shared handle; a second object of the same kind gets a
+# handle of its own (its state must be separate), and stateless uses ("stateless": InvKin, the fixed-base foot kinematics, the
+# base inertia) share without limit.  A family is handed out once per shared handle, never recycled: a new object must start
+# from the state a fresh handle has.
+_shared_batch1 = {}  # configuration -> (Batch, set of families handed out)
+
+
+def shared_batch1(family, n_steps=16, N_gait=20, dt_mpc=0.02, T_gait=0.32, dt_wbc=0.002, device=0):
+    """The process-wide batch-1 `Batch` of this configuration if `family` ("mpc", "wbc" or "stateless") is still free on it,
+    a private one otherwise."""
+    if family not in ("mpc", "wbc", "stateless"):
+        raise QrwError("unknown state family %r" % (family,))
+    key = (int(n_steps), int(N_gait), float(dt_mpc), float(T_gait), float(dt_wbc), int(device))
+    ent = _shared_batch1.get(key)
+    if ent is None:
+        ent = _shared_batch1[key] = (Batch(1, n_steps=key[0], N_gait=key[1], dt_mpc=key[2], T_gait=key[3], dt_wbc=key[4],
+                                           device=key[5]), set())
+    b, taken = ent
+    if family == "stateless":
+        return b
+    if family in taken:
+        return Batch(1, n_steps=key[0], N_gait=key[1], dt_mpc=key[2], T_gait=key[3], dt_wbc=key[4], device=key[5])
+    taken.add(family)
+    return b
 
 
 class StreamGroups:

@@ -14,7 +14,7 @@ class Solo12InvKin:
     def __init__(self, dt):
         self.dt = dt
         self.InvKinCpp = lrw.InvKin(dt)
-        self._kin = qrw_hip.Batch(1, dt_wbc=float(dt))
+        self._kin = qrw_hip.shared_batch1("stateless", dt_wbc=float(dt))
 
         # Memory assignation for variables (scripts/solo12InvKin.py:19-28)
         self.cpp_posf = np.zeros((4, 3))

@@ -21,7 +21,7 @@ def run(**kw):
 
 
 def run_(**kw):
-    ctl = Controller_batch(B, q_init, **kw)
+    ctl = Controller_batch(B, q_init, groups=1, **kw)
     vref = torch.from_numpy(vref_h).to(dev)
     qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
     qf[:, 7:] = torch.from_numpy(q_init).to(dev)

@@ -25,7 +25,7 @@ def new_vref(scale):
 
 
 with torch.cuda.stream(torch.cuda.Stream(dev)):
-    ctl = Controller_batch(B, q_init, multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=max(20, N + 4))
+    ctl = Controller_batch(B, q_init, groups=1, multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=max(20, N + 4))
     vref = new_vref(0.5)
     qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
     qf[:, 7:] = torch.from_numpy(q_init).to(dev)

@@ -8,7 +8,7 @@ from Controller import Controller_batch
 B = int(os.environ.get("QRW_EXP_B", "4096"))
 dev = torch.device("cuda:0")
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
-ctl = Controller_batch(B, q_init, fused=(len(sys.argv) < 2 or sys.argv[1] != 'separate'))
+ctl = Controller_batch(B, q_init, groups=1, fused=(len(sys.argv) < 2 or sys.argv[1] != 'separate'))
 vref = torch.zeros((B, 6), dtype=torch.float64, device=dev); vref[:, 0] = 0.4
 qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
 qf[:, 7:] = torch.from_numpy(q_init).to(dev)

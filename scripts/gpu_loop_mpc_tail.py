@@ -10,7 +10,7 @@ B, N = 4096, 16
 dev = torch.device("cuda:0")
 sb = synth.SyntheticBatch(B, N, N_gait=20, gaits=("trot",), n_seq=2)
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
-ctl = Controller_batch(B, q_init)
+ctl = Controller_batch(B, q_init, groups=1)
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 vref = torch.from_numpy(np.ascontiguousarray(scale * sb.vref)).to(dev)
 qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0

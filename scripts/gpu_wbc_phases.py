@@ -10,7 +10,7 @@ from Controller import Controller_batch
 B = 4096
 dev = torch.device("cuda:0")
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])
-ctl = Controller_batch(B, q_init)
+ctl = Controller_batch(B, q_init, groups=1)
 rng = np.random.default_rng(3)
 vref = torch.from_numpy(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0])).to(dev)
 qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0

@@ -226,3 +226,51 @@ def test_known_answers_do_not_depend_on_what_other_kernels_left_in_lds(pattern):
             it, st, rho, err = C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
             rc = lib.qrw_test_known_answer(N, mode, pattern, 1, C.byref(it), C.byref(st), C.byref(rho), C.byref(err))
             assert rc == 0, (mode, N, rc, it.value, st.value, rho.value, err.value)
+
+
+def test_getters_and_host_calls_wait_for_their_own_handle_only(synth_mod):
+    """Synchronisation is per handle (include/qrw_hip.h, conventions): while handle B's long N = 32 launch runs on a BLOCKING
+    stream (a compute-unit-masked one: the legacy default stream and every blocking copy synchronise with it), handle A's
+    getters (`mpc_stats`, `wbc_stats`, `mpc_gait`), a `_host` solve and the creation of a third handle all return -- B's
+    event has not completed when they are back.  B's own getter then waits for B.  Before round 5 every one of these calls
+    ended in hipDeviceSynchronize."""
+    import time
+
+    import torch
+    import qrw_hip
+
+    n_cu = qrw_hip.device_cu_count(0)
+    N2, Ng2, B2 = 32, 36, 4096
+    sb2 = synth_mod.SyntheticBatch(B2, N2, N_gait=Ng2, gaits=("walk", "trot", "bounding"), seed0=515000)
+    d2 = sb2.step(0)
+    x2, f2 = torch.from_numpy(d2["xref"]).cuda(), torch.from_numpy(d2["fsteps"]).cuda()
+    big = qrw_hip.Batch(B2, n_steps=N2, N_gait=Ng2, T_gait=0.02 * N2)
+    out2 = torch.empty((B2, 24, N2), dtype=torch.float64, device="cuda")
+    sb1 = synth_mod.SyntheticBatch(4, 16, seed0=516000)
+    d1 = sb1.step(0)
+    small = qrw_hip.Batch(4, 16)
+    ref = small.mpc_solve_host(d1["xref"], d1["fsteps"], 0)   # (also: A's state families have launched once)
+    small.wbc_compute_host(d1["q"], d1["dq"], np.ascontiguousarray(ref[:, 12:, 0]), d1["contacts"], d1["pgoals"], d1["vgoals"], d1["agoals"])
+    side = qrw_hip.CuStream(0, 0, n_cu // 2)  # half the chip, so that A's kernels find free compute units at once
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side.torch):
+        big.mpc_solve(x2, f2, 0, out=out2)
+        done.record(side.torch)
+    t0 = time.perf_counter()
+    st = small.mpc_stats()
+    ws = small.wbc_stats()
+    gait, _ = small.mpc_gait(0)
+    again = small.mpc_solve_host(d1["xref"], d1["fsteps"], 0)
+    third = qrw_hip.Batch(2, 16)
+    t1 = time.perf_counter()
+    still_running = not done.query()
+    bst = big.mpc_stats()                      # B's own getter: waits for B's launch (on the masked stream)
+    assert done.query()
+    assert still_running, "handle A's calls took %.1f ms and outlived handle B's launch" % (1e3 * (t1 - t0))
+    assert (st["status"] == 1).all() and (ws["status"] == 1).all() and gait.shape == (20, 4)
+    assert np.array_equal(again, ref)          # same inputs, num_iter 0: the cold solve again
+    assert np.isin(bst["status"], (1, 2, -2)).all() and (bst["iters"] > 0).all()
+    third.close()
+    side.close()
+    assert (big.mpc_stats()["iters"] == bst["iters"]).all()  # the stream is gone: the getter has nothing to wait for and says the same

@@ -105,25 +105,43 @@ def _shift_last_available(res, gait, n_steps):
                 res[12 + 3 * i + 2, n_steps - 1] = F
 
 
-def _closed_loop(oracle_mod, mode, fused, cfg, iters):
+def test_async_closed_loop_on_the_quad_wbc_kernel(oracle_mod):
+    """The asynchronous mode at a batch where Controller_batch picks wbc_kernel's full mode by itself (one quad per robot:
+    the loop's stream owns too few SIMDs for wbc16_kernel's batch / 4 wavefronts, Controller.py `wbc_set_lanes(4)`; every batch
+    above 128 with the default loop_cus): the closed loop against the chained oracles on a spread of instances -- first and last
+    rows of a wavefront's sixteen quads, both sides of a wavefront boundary, the last instance."""
+    _closed_loop(oracle_mod, "async_lag3", True, DEFAULT_CFG, 45, B=160, check=(0, 1, 15, 16, 63, 64, 131, 159), want_lanes=4)
+
+
+def test_closed_loop_with_the_thread_form_of_control_pre(oracle_mod, monkeypatch):
+    """qrw_control_pre's one-thread-per-robot form (QRW_PRE_QUAD=0, an A/B knob read per call) in the closed loop against the
+    chained oracles: the knob's other position stands under the oracle too, not only under the quad form."""
+    monkeypatch.setenv("QRW_PRE_QUAD", "0")
+    _closed_loop(oracle_mod, "sync", True, DEFAULT_CFG, 45)
+
+
+def _closed_loop(oracle_mod, mode, fused, cfg, iters, B=5, check=None, want_lanes=None):
     """Controller_batch (planners -> MPC every 10th -> glue -> WBC -> result, all on the device) against the same chain
     made of the CPU oracles, with the measurements fed back from the oracle's own desired joint state.  The
     asynchronous modes run the MPC on its own compute-unit-masked stream and adopt a result a fixed number of
-    iterations after it was issued (lag 0 = the synchronous semantics)."""
+    iterations after it was issued (lag 0 = the synchronous semantics).  check: the instances compared with the oracle
+    (default all); the others are fed back their own device results."""
     import torch
     import controller_oracle as co
     from Controller import Controller_batch
 
-    B = 5
     k_mpc, n_steps = cfg["k_mpc"], int(round(cfg["T_mpc"] / cfg["dt_mpc"]))
     lag = {"sync": 0, "async_lag0": 0, "async_lag3": 3}[mode]
     rng = np.random.default_rng(3)
-    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag, fused=fused, **cfg)
-    glue = [co.ControllerGlue(Q_INIT, cfg["h_ref"], cfg["dt_wbc"]) for _ in range(B)]
-    plan = [oracle_mod.Planner(dt_mpc=cfg["dt_mpc"], dt_wbc=cfg["dt_wbc"], T_gait=cfg["T_gait"], T_mpc=cfg["T_mpc"],
-                               N_gait=cfg["N_gait"], k_mpc=k_mpc, h_ref=cfg["h_ref"]) for _ in range(B)]
-    mpc = [oracle_mod.MPC(cfg["dt_mpc"], n_steps, cfg["T_gait"], cfg["N_gait"]) for _ in range(B)]
-    wbc = [oracle_mod.WbcController(cfg["dt_wbc"]) for _ in range(B)]
+    ctl = Controller_batch(B, Q_INIT, multiprocessing=(mode != "sync"), mpc_lag=lag, fused=fused, groups=1, **cfg)
+    if want_lanes is not None:
+        assert ctl.wbc_lanes == want_lanes
+    check = tuple(range(B)) if check is None else tuple(check)
+    glue = {b: co.ControllerGlue(Q_INIT, cfg["h_ref"], cfg["dt_wbc"]) for b in check}
+    plan = {b: oracle_mod.Planner(dt_mpc=cfg["dt_mpc"], dt_wbc=cfg["dt_wbc"], T_gait=cfg["T_gait"], T_mpc=cfg["T_mpc"],
+                                  N_gait=cfg["N_gait"], k_mpc=k_mpc, h_ref=cfg["h_ref"]) for b in check}
+    mpc = {b: oracle_mod.MPC(cfg["dt_mpc"], n_steps, cfg["T_gait"], cfg["N_gait"]) for b in check}
+    wbc = {b: oracle_mod.WbcController(cfg["dt_wbc"]) for b in check}
     first = np.zeros((24, n_steps))
     first[2, 0] = cfg["h_ref"]
     first[12:, 0] = [0.0, 0.0, 8.0] * 4
@@ -146,7 +164,8 @@ def _closed_loop(oracle_mod, mode, fused, cfg, iters):
         got = ctl._res["result"].cpu().numpy()
         flags = ctl.error_flag.cpu().numpy()
         nq, nv = qf.copy(), vf.copy()
-        for b in range(B):
+        nq[:, 7:], nv[:, 6:] = got[:, 2], got[:, 3]  # instances outside `check`: their own device targets
+        for b in check:
             g = glue[b]
             oRh, oTh = g.update_state(vref[b], qf[b], vf[b], rpy[b])
             plan[b].step(k, g.q[:7, 0], g.h_v[:6, 0], g.v_ref[:6, 0], 0)
@@ -365,17 +384,19 @@ def test_stream_groups_controller_equals_the_single_handle(mode):
         Controller_batch(7, Q_INIT, groups=2)
 
 
-@pytest.mark.parametrize("free", [False, True])
-def test_staggered_stream_groups_equal_single_handles_started_late(free):
+@pytest.mark.parametrize("free,defaults", [(False, False), (True, False), (False, True)], ids=["joined", "free", "default_object"])
+def test_staggered_stream_groups_equal_single_handles_started_late(free, defaults):
     """Controller_batch(..., groups=2, stagger=True): group 1 starts k_mpc / 2 fleet ticks late, so the two groups' MPC solves fall
     on different ticks (the reference solves on k % k_mpc == 0 of the robot's own clock, scripts/Controller.py:246-253).  Every
     robot must see exactly a single-handle controller started that many ticks later: Result and error flag of group g at fleet
     tick t equal, bit for bit, those of a single handle over the group's robots at its tick t - delay; before its start a
-    group's slice of the result is zero.  Joined (compute) and never joined (compute_group on the groups' streams)."""
+    group's robots are commanded to hold q_init (P 3, D 0.2, zero v_des / tau_ff).  Joined (compute) and never joined
+    (compute_group on the groups' streams).  default_object: a fleet of 2048 robots built WITHOUT groups / stagger arguments is
+    exactly that object (auto_groups), a fleet below that size a single handle."""
     import torch
     from Controller import Controller_batch, Controller_groups
 
-    B, iters, k_mpc = 32, 27, 10
+    B, iters, k_mpc = (2048, 23, 10) if defaults else (32, 27, 10)
     rng = np.random.default_rng(11)
     qi = Q_INIT + rng.uniform(-0.03, 0.03, (B, 12))
     vref = _t(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0]))
@@ -388,8 +409,14 @@ def test_staggered_stream_groups_equal_single_handles_started_late(free):
         vf = torch.zeros((n, 18), dtype=torch.float64, device="cuda")
         return qf, vf, torch.zeros((n, 3), dtype=torch.float64, device="cuda"), torch.zeros((n, 12), dtype=torch.float64, device="cuda")
 
-    ctl = Controller_batch(B, qi, groups=2, stagger=True, k_mpc=k_mpc)
-    assert isinstance(ctl, Controller_groups) and ctl._delay == [0, k_mpc // 2]
+    if defaults:
+        ctl = Controller_batch(B, qi)
+        assert not isinstance(Controller_batch(2046, Q_INIT), Controller_groups)        # below the threshold: one handle
+        assert not isinstance(Controller_batch(B, Q_INIT, groups=1), Controller_groups)  # groups=1 stays available
+        assert not Controller_batch(B, Q_INIT, groups=2).stagger                         # explicit groups: not staggered unless asked
+    else:
+        ctl = Controller_batch(B, qi, groups=2, stagger=True, k_mpc=k_mpc)
+    assert isinstance(ctl, Controller_groups) and ctl.G == 2 and ctl.stagger and ctl._delay == [0, k_mpc // 2]
     qf, vf, rpy, vs = state(B, qi)
     vf[:, :6] = vref
     hist = []
@@ -422,8 +449,10 @@ def test_staggered_stream_groups_equal_single_handles_started_late(free):
         q1, v1, rpy1, vs1 = state(B // 2, qi[sl])
         v1[:, :6] = vref[sl]
         for t in range(iters):
-            if t < d:
-                assert float(hist[t][sl].abs().max()) == 0.0
+            if t < d:  # not started: hold q_init with the controller's own PD gains
+                hold = hist[t][sl]
+                assert bool((hold[:, 0] == 3.0).all()) and bool((hold[:, 1] == 0.2).all()) and torch.equal(hold[:, 2], _t(qi[sl]))
+                assert float(hold[:, 3:].abs().max()) == 0.0
                 continue
             r = one.compute(vref[sl], q1, v1, rpy1, vs1, code[sl])
             q1[:, 7:].copy_(r.q_des)

@@ -21,12 +21,20 @@ def f_cmd_for(contacts, rng=None):
     return f
 
 
-def test_wbc_sequence_matches_oracle(oracle_mod, synth_mod):
+# Both shipped forms of the full WBC step stand directly under the oracle: wbc16_kernel (16 lanes per robot, the default) and
+# wbc_kernel's full mode (one quad per robot: what Controller_batch(multiprocessing=True) selects by itself above batch 128,
+# Controller.py `wbc_set_lanes(4)`; reference: scripts/QP_WBC.py:52-131, src/QPWBC.cpp:310-390).
+LANES = pytest.mark.parametrize("lanes", [16, 4], ids=["wbc16_kernel", "wbc_kernel_quad"])
+
+
+@LANES
+def test_wbc_sequence_matches_oracle(oracle_mod, synth_mod, lanes):
     import qrw_hip
 
     B = 21  # not a multiple of 16: exercises the padded quads of the last wavefront
     sb = synth_mod.SyntheticBatch(B, 16, gaits=("trot", "walk", "static"), seed0=91000)
     eng = qrw_hip.Batch(B)
+    eng.wbc_set_lanes(lanes)
     refs = [oracle_mod.WbcController(0.002) for _ in range(B)]
     rng = np.random.default_rng(0)
     for s in range(8):
@@ -164,7 +172,8 @@ def test_async_wrapper_returns_previous_then_new_result(synth_mod):
         assert np.array_equal(a, b)
 
 
-def test_contact_patterns_from_flight_to_full_stance(oracle_mod, synth_mod):
+@LANES
+def test_contact_patterns_from_flight_to_full_stance(oracle_mod, synth_mod, lanes):
     """Every one of the 16 contact sets (flight phase, single support, ..., four feet), changing from call to call on
     the same solver instance (the QP's matrix changes, the warm start is kept): GPU vs oracle."""
     import qrw_hip
@@ -172,6 +181,7 @@ def test_contact_patterns_from_flight_to_full_stance(oracle_mod, synth_mod):
     B = 16
     sb = synth_mod.SyntheticBatch(B, 16, gaits=("trot",), seed0=93000)
     eng = qrw_hip.Batch(B)
+    eng.wbc_set_lanes(lanes)
     refs = [oracle_mod.WbcController(0.002) for _ in range(B)]
     rng = np.random.default_rng(5)
     for s in range(4):
@@ -325,9 +335,9 @@ def test_stream_groups_give_the_single_handle_results(synth_mod):
 
 
 def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
-    """MPC_Wrapper_batch(..., groups=2) (two handles on two streams, opt-in) returns what the
-    single handle returns, bit for bit, for int and per-instance iteration arguments, incl. the default result before the
-    first solve and replay_batch."""
+    """MPC_Wrapper_batch WITHOUT a groups argument on a fleet of 2052 robots (two handles on two streams: the default from 2048
+    robots on) returns what the single handle (groups=1) returns, bit for bit, for int and per-instance iteration arguments,
+    incl. the default result before the first solve."""
     import torch
 
     import MPC_Wrapper
@@ -335,8 +345,9 @@ def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
     B, N, K = 2052, 16, 4
     sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=99200)
     a = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=1)
-    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=2)
+    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B)
     assert a.G == 1 and b.G == 2 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 8).G == 1
+    assert MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 2046).G == 1 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 64, groups=2).G == 2
     assert torch.equal(a.get_latest_result_batch(), b.get_latest_result_batch())  # the default forces
     for s in range(K):
         d = sb.step(s)
