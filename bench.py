@@ -31,6 +31,11 @@ sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 # process uses more than four over its legs, and two stream groups that land on one queue serialise (DESIGN.md 4.1:
 # 600 k instead of 970 k steps/s).  Read by the runtime at its first call: set before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the CPU baseline's OpenMP threads (oracle/) stay on the cores they start on: read by libgomp when it initialises, i.e. at the
+# first import that pulls it in (torch) -- hence here.  cpu_baseline reports it as "pinned".
+if os.environ.get("WORLD_SIZE", "1") == "1":  # (only the single-process run times the CPU baseline; ranks of a multi-GPU job would
+    os.environ.setdefault("OMP_PROC_BIND", "close")  # all bind to the same first cores)
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 
@@ -377,11 +382,19 @@ def main():
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
             # 32 compute units for the loop's stream: the highest free-running rate, paid for in iteration latency
             out["secondary_ratio_1_10_async_32cu"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True, loop_cus=32)
+            # what Controller_batch(B, ...) builds without arguments at this fleet size (two staggered stream groups, joined per iteration)
+            out["secondary_ratio_1_10_default_object"] = device_resident_loop(sb, B, N, N_gait, dev, groups=None)
+            if (N, gaits) == (16, ("trot",)):
+                out["realtime_slot"] = realtime_slot_leg(sb, N, N_gait, dev)
         if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
             # the metric reads "batch {1, 256, 4096}" and BASELINE lists configs 2 and 4: every single-GPU figure in this ONE line
-            out["batch_1"] = config_leg(1, 16, ("trot",), dev, W=3, K=20)
-            out["batch_256_mpc_only"] = config_leg(256, 16, ("trot",), dev, W=3, K=20, mpc_only=True)
-            out["config4_n32_mixed"] = config_leg(4096, 32, ("walk", "trot", "bounding"), dev, W=3, K=6, closed=True, groups=2)
+            # each leg carries the metric's accuracy half too: the HIP path against the CPU oracle on a bounded sample of the
+            # leg's own workload (first `acc[0]` instances x `acc[1]` control steps), outside every timed region
+            thr = args.cpu_threads
+            out["batch_1"] = config_leg(1, 16, ("trot",), dev, W=3, K=20, acc=(1, 23), threads=thr)
+            out["batch_256_mpc_only"] = config_leg(256, 16, ("trot",), dev, W=3, K=20, mpc_only=True, acc=(256, 8), threads=thr)
+            out["config4_n32_mixed"] = config_leg(4096, 32, ("walk", "trot", "bounding"), dev, W=3, K=6, closed=True, groups=2,
+                                                  acc=(128, 6), threads=thr)
         if not args.no_cpu_baseline:
             base, ref_out = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
             out["cpu_baseline"] = base
@@ -393,7 +406,7 @@ def main():
         dist.destroy_process_group()
 
 
-def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0):
+def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0, acc=None, threads=16):
     """One BASELINE configuration other than the headline's, timed in-line on a FRESH handle with the headline's method:
     W untimed warm-up steps (the first one sets the QPs up), K timed steps bracketed by synchronisation, HIP events around
     every mpc_solve launch, the ADMM iteration counts of every timed launch (device-to-device), FP64 fraction with THIS
@@ -493,6 +506,63 @@ def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0):
         c = timed(cseq, "closed receding-horizon sequence (SURVEY 8(d))")
         res["closed_loop"] = {k: c[k] for k in ("value", "unit", "ms_per_step", "launch_ms_mean", "mean_admm_iters", "max_admm_iters",
                                                 "max_iter_exit_share", "roofline_frac")}
+    if acc:
+        res["accuracy"] = leg_accuracy(acc[0], acc[1], N, N_gait, gaits, mpc_only, dev, threads)
+    return res
+
+
+def leg_accuracy(Bc, steps, N, N_gait, gaits, mpc_only, dev, threads):
+    """The metric's accuracy half for one configuration leg: the first Bc instances of the leg's workload (instance seeds are
+    per robot, so these ARE the leg's robots) x `steps` control steps from the set-up call on, HIP path against the CPU oracle
+    on identical inputs: MPC result, and -- unless the leg is MPC-only -- joint torques and contact forces; ADMM iteration
+    counts compared solve by solve.  Outside every timed region (the oracle is the checker here, never the thing measured)."""
+    import torch
+
+    import qrw_hip
+    import synth
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build(fast=True)
+    cores = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+    sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps)
+    eng = qrw_hip.Batch(Bc, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
+    mpc = oracle.MPCBatch(Bc, 0.02, N, 0.02 * N, N_gait, fast=True)
+    wbc = None if mpc_only else oracle.WbcBatch(Bc, 0.002, fast=True)
+    x_abs = x_ref = tau_abs = tau_ref = f_abs = f_ref = 0.0
+    it_mismatch = solves = 0
+    t_cpu = 0.0
+    for s in range(steps):
+        d = sb.step(s)
+        t = {k: torch.from_numpy(np.ascontiguousarray(d[k])).to(dev) for k in
+             ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")}
+        o = eng.mpc_solve(t["xref"], t["fsteps"], s)
+        a = time.perf_counter()
+        r = mpc.run(s, d["xref"], d["fsteps"], cores)
+        t_cpu += time.perf_counter() - a
+        og = o.cpu().numpy()
+        it_ref, _ = mpc.iters()
+        it_mismatch += int((eng.mpc_stats()["iters"] != it_ref).sum())
+        solves += Bc
+        x_abs, x_ref = max(x_abs, float(np.abs(og - r).max())), max(x_ref, float(np.abs(r).max()))
+        if not mpc_only:
+            w = eng.wbc_compute(t["q"], t["dq"], o[:, 12:, 0].contiguous(), t["contacts"], t["pgoals"], t["vgoals"], t["agoals"])
+            tau, _, _, f = wbc.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"],
+                                       d["vgoals"], d["agoals"], cores)
+            tg, fg = w["tau_ff"].cpu().numpy(), w["f_with_delta"].cpu().numpy()
+            tau_abs, tau_ref = max(tau_abs, float(np.abs(tg - tau).max())), max(tau_ref, float(np.abs(tau).max()))
+            f_abs, f_ref = max(f_abs, float(np.abs(fg - f).max())), max(f_ref, float(np.abs(f).max()))
+    eng.close()
+    rel = [x_abs / x_ref] + ([] if mpc_only else [tau_abs / tau_ref, f_abs / f_ref])
+    res = {"mpc_result_max_abs_err": x_abs, "mpc_result_max_rel_err": x_abs / x_ref,
+           "admm_iteration_count_mismatches": it_mismatch, "solves_compared": solves, "tolerance_rel": 1e-4,
+           "within_tolerance": bool(max(rel) < 1e-4),
+           "sample": "first %d instances x %d control steps (from the set-up call on) of this leg's workload, HIP path vs CPU oracle "
+                     "(oracle/, %d threads, %.1f s), max over instances and steps; relative = max abs error / max abs reference"
+                     % (Bc, steps, cores, t_cpu)}
+    if not mpc_only:
+        res.update({"torque_max_abs_err": tau_abs, "torque_max_rel_err": tau_abs / tau_ref, "force_max_rel_err": f_abs / f_ref,
+                    "torque_scale_Nm": tau_ref})
     return res
 
 
@@ -754,7 +824,7 @@ def closed_loop_sequence(B, N, N_gait, gaits, dev, W, K):
 
 
 def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocessing=False, loop_cus=None, groups=1, free_running=False,
-                         stagger=False):
+                         stagger=False, on_loop_stream=False):
     """Secondary figure: the reference's own 1:10 MPC:WBC ratio, whole Controller.compute iterations
     (scripts/Controller.py:200-326) on the device — updateState, the four planners, one MPC solve every k_mpc
     iterations, WBC target assembly, InvKin + QPWBC, result + security check — nothing leaving HBM.
@@ -773,7 +843,13 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
     with torch.cuda.stream(torch.cuda.Stream(dev)):
         ctl = Controller_batch(B, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=k_mpc, T_gait=0.02 * N, T_mpc=0.02 * N,
                                N_gait=N_gait, device=dev.index or 0, multiprocessing=multiprocessing, loop_cus=loop_cus,
-                               groups=groups, stagger=stagger)
+                               groups=groups, stagger=(None if groups is None else stagger))
+        groups, stagger = getattr(ctl, "G", 1), getattr(ctl, "stagger", False)  # (groups=None: what the object chose by itself)
+        # on_loop_stream (asynchronous mode): the caller's own work (the stand-in for the robots below) runs on the control loop's
+        # stream, which saves compute() the hand-over between two streams (Controller_batch.loop_stream)
+        import contextlib
+        ctx = torch.cuda.stream(ctl.loop_stream) if (on_loop_stream and multiprocessing and groups == 1) else contextlib.nullcontext()
+        ctx.__enter__()
         # half the joystick range of the headline workload: at up to 1.5 m/s a sixth of the instances run into the
         # controller's joint-limit / torque security stop within 100 iterations (reference behaviour), which would
         # make the figure depend on how many robots have already been stopped
@@ -786,17 +862,30 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
         rpy = torch.zeros((B, 3), dtype=torch.float64, device=dev)
         vs = torch.zeros((B, 12), dtype=torch.float64, device=dev)
 
+        host_us = []  # host time of the compute() calls alone (enqueue, no synchronisation), with whether the iteration solved
+        gv = [tuple(a[ctl.slice_of(g)] for a in (vref, qf, vf, rpy, vs)) for g in range(groups)] if (free_running and groups > 1) else None
+
         def it():
             if free_running and groups > 1:
                 for g in range(groups):
                     sl = ctl.slice_of(g)
                     with torch.cuda.stream(ctl.stream_of(g)):
-                        r = ctl.compute_group(g, vref[sl], qf[sl], vf[sl], rpy[sl], vs[sl])
+                        r = ctl.compute_group(g, *gv[g])
                         if ctl.group_started(g):
                             qf[sl, 7:].copy_(r.q_des)
                             vf[sl, 6:].copy_(r.v_des)
                 return
+            solving = any(((ctl.k - dly) % k_mpc) == 0 for dly in getattr(ctl, "_delay", [0]))
+            t0 = time.perf_counter()
             r = ctl.compute(vref, qf, vf, rpy, vs)
+            host_us.append((1e6 * (time.perf_counter() - t0), solving))
+            if groups > 1 and not all(ctl.group_started(g) for g in range(groups)):
+                for g in range(groups):  # a staggered group that has not started holds q_init: nothing to feed back yet
+                    if ctl.group_started(g):
+                        sl = ctl.slice_of(g)
+                        qf[sl, 7:].copy_(r.q_des[sl])
+                        vf[sl, 6:].copy_(r.v_des[sl])
+                return
             qf[:, 7:].copy_(r.q_des)  # perfect tracking of the PD targets stands in for the robot
             vf[:, 6:].copy_(r.v_des)
 
@@ -826,8 +915,10 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
             wait_iteration()
             lat.append(time.perf_counter() - a)
         bad = int((ctl.error_flag != 0).sum().item())
+        ctx.__exit__(None, None, None)
         ctl.stop_parallel_loop()
     lat = 1e3 * np.array(lat)
+    ns = np.array([t for t, sv in host_us[2 * k_mpc:] if not sv])
     what = ("whole Controller.compute iterations (state update, planners, glue, WBC every iteration, MPC every %d-th), "
             "device-resident, batch %d, reference velocities = half the headline workload's" % (k_mpc, B))
     if groups > 1:
@@ -840,7 +931,74 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
                  "with the other 32, a result adopted when its event has completed")
     return {"value": B * iters / el, "unit": "control iterations/s", "iterations": iters, "k_mpc": k_mpc,
             "ms_per_iteration": 1e3 * el / iters, "paced_2ms_latency_ms": {"median": float(np.median(lat)), "worst": float(lat.max())},
+            "host_us_per_nonsolving_compute": ({"median": float(np.median(ns)), "p90": float(np.percentile(ns, 90))} if len(ns) else None),
             "instances_in_security_stop": bad, "what": what}
+
+
+def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 4096)):
+    """How many robots fit the reference's real-time slot: the 1:10 loop (scripts/Controller.py:246, dt_wbc = 2 ms,
+    src/config_solo12.yaml:6) paced at 2 ms for a growing fleet, in the synchronous mode (the iteration that solves carries the
+    whole MPC launch), as the default object builds it (two staggered stream groups from 2048 robots on) and in the asynchronous
+    mode (the solve on its own compute units; the caller on the loop's stream): median / worst time from the call of compute() to
+    its PD targets being ready, host time of a compute() that does not solve, and the largest fleet whose WORST iteration stays
+    inside the slot."""
+    import synth
+
+    rows = []
+    for B in batches:
+        sb = sb_full if B == sb_full.B else synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=("trot",), n_seq=1)
+        row = {"batch": B}
+        for name, kw in (("sync", dict(groups=1)), ("default_object", dict(groups=None)),
+                         ("async", dict(groups=1, multiprocessing=True, on_loop_stream=True))):
+            if name == "default_object" and B < 2048:
+                continue  # (the default object IS the single handle below 2048 robots)
+            r = device_resident_loop(sb, B, N, N_gait, dev, **kw)
+            row[name] = {"paced_median_ms": r["paced_2ms_latency_ms"]["median"], "paced_worst_ms": r["paced_2ms_latency_ms"]["worst"],
+                         "host_us_per_nonsolving_compute": r["host_us_per_nonsolving_compute"],
+                         "free_running_M_iterations_per_s": r["value"] / 1e6, "stopped": r["instances_in_security_stop"]}
+        rows.append(row)
+    fits = {}
+    for name in ("sync", "default_object", "async"):
+        ok = [r["batch"] for r in rows if (name in r or (name == "default_object" and "sync" in r))
+              and (r.get(name) or r["sync"])["paced_worst_ms"] < 2.0]
+        fits[name] = max(ok) if ok else None
+    return {"slot_ms": 2.0, "k_mpc": 10, "rows": rows, "largest_batch_with_worst_iteration_inside_the_slot": fits,
+            "what": "1:10 control loop paced at dt_wbc = 2 ms, 40 paced iterations (4 of them solve) after 20 warm-up and 40 free-running "
+                    "ones; latency = compute() call until the iteration's PD targets are ready (incl. the two copies that stand in for "
+                    "the robots); batches tested: %s" % (list(batches),)}
+
+
+def host_cpu_info():
+    """What the CPU baseline ran on: model name, logical CPUs of the box and of this process, clocks from /proc/cpuinfo."""
+    info = {"model": None, "logical_cpus": os.cpu_count(), "cpus_allowed": len(os.sched_getaffinity(0)), "mhz_now_max": None,
+            "mhz_max": None}
+    try:
+        mhz = []
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and info["model"] is None:
+                info["model"] = ln.split(":", 1)[1].strip()
+            elif ln.startswith("cpu MHz"):
+                mhz.append(float(ln.split(":", 1)[1]))
+        if mhz:
+            info["mhz_now_max"] = max(mhz)
+    except Exception:
+        pass
+    try:
+        info["mhz_max"] = int(open("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq").read()) / 1e3
+    except Exception:
+        pass
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except Exception:
+        pass
+    return info
+
+
+def omp_pinned():
+    """True when the OpenMP runtime was told to bind the oracle's threads to places (OMP_PROC_BIND, set at the top of this
+    file unless the caller's environment says otherwise)."""
+    v = os.environ.get("OMP_PROC_BIND", "").lower()
+    return v not in ("", "false", "0")
 
 
 def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps):
@@ -870,19 +1028,26 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps):
             t_mpc += b - a
             t_wbc += c - b
     tot = t_mpc + t_wbc
-    # BASELINE config 1: a single robot on a single thread (the reference's own deployment shape)
+    # BASELINE config 1: a single robot on a single thread (the reference's own deployment shape); best of three passes
+    # (the figure moved by 23 % between two rounds' boxes on unchanged code: a shared host)
     sb1 = synth.SyntheticBatch(1, N, N_gait=N_gait, gaits=gaits, n_seq=33)
-    m1, w1 = oracle.MPCBatch(1, 0.02, N, 0.02 * N, N_gait, fast=True), oracle.WbcBatch(1, 0.002, fast=True)
-    t1 = 0.0
-    for s in range(33):
-        d = sb1.step(s)
-        a = time.perf_counter()
-        r = m1.run(s, d["xref"], d["fsteps"], 1)
-        w1.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"], 1)
-        if s > 0:
-            t1 += time.perf_counter() - a
+    seq1 = [sb1.step(s) for s in range(33)]
+    t1s = []
+    for _ in range(3):
+        m1, w1 = oracle.MPCBatch(1, 0.02, N, 0.02 * N, N_gait, fast=True), oracle.WbcBatch(1, 0.002, fast=True)
+        t1 = 0.0
+        for s, d in enumerate(seq1):
+            a = time.perf_counter()
+            r = m1.run(s, d["xref"], d["fsteps"], 1)
+            w1.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"], 1)
+            if s > 0:
+                t1 += time.perf_counter() - a
+        t1s.append(t1)
+    t1 = min(t1s)
     return ({"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
+             "host_cpu": host_cpu_info(), "pinned": omp_pinned(),
              "single_instance_single_thread_steps_per_s": 32 / t1,
+             "single_instance_single_thread_passes_steps_per_s": [32 / t for t in t1s],
              "sample": "%d instances x %d control steps (after the set-up step) of the headline sequence, %.1f s of CPU work; "
                        "CPU restatement oracle/ (OSQP-0.6-style, not OSQP itself), gcc -O3 -march=native, OpenMP one instance "
                        "per thread" % (Bc, steps, tot),

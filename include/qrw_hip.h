@@ -287,6 +287,29 @@ int qrw_wbc_compute_result(qrw_handle h, const double *d_q, const double *d_dq, 
                            double *d_f_with_delta, double *d_ddq_res, double *d_feet, const double *d_q_filt,
                            const double *d_v_secu, double *d_result, int32_t *d_error_flag, void *stream);
 
+/* A control iteration that does not solve (qrw_control_pre given d_x_f_mpc, without d_fsteps / d_gait, + qrw_wbc_compute_result
+ * on its outputs) with every buffer BOUND ONCE: a control loop passes the same buffers on every tick -- the sensor values are
+ * written into fixed input arrays, the outputs read from fixed ones -- so the ~50 pointer arguments of the two calls need not be
+ * marshalled again every 2 ms (scripts/Controller.py:200-326 runs 9 of 10 iterations this way, :246).  qrw_iteration_bind stores
+ * the pointers in the handle (no launch, no allocation; binding again replaces them); qrw_iteration_step enqueues the two launches
+ * for iteration k on `stream` using the MPC result d_x_f_mpc [B][24][N] (whichever buffer the loop has adopted).  Same kernels,
+ * same arithmetic as the two separate calls.  Why not a HIP graph: on this runtime hipGraphLaunch of the captured pair costs
+ * 19 us of host time against 8.6-9.3 us for the two launches (scripts/ubench/graph_launch.hip, profiles/r5_graph_launch.txt). */
+typedef struct {
+  /* inputs (read every step) */
+  const double *d_joy_vref, *d_q_filt, *d_v_filt, *d_rpy, *d_v_secu;
+  const int32_t *d_code; /* per-robot joystick codes or NULL */
+  int32_t code_scalar;   /* used when d_code is NULL         */
+  /* outputs of qrw_control_pre (d_fsteps / d_gait are not produced on an iteration that does not solve) */
+  double *d_q, *d_v, *d_hv, *d_vref, *d_oRh_oTh, *d_xref, *d_target, *d_feet_pva, *d_contacts, *d_x_f_wbc, *d_q_wbc, *d_b_v,
+      *d_f_cmd, *d_feet_cmd;
+  /* outputs of qrw_wbc_compute_result */
+  double *d_tau_ff, *d_qdes, *d_vdes, *d_f_with_delta, *d_ddq_res, *d_feet, *d_result;
+  int32_t *d_error_flag;
+} qrw_iteration_buffers;
+int qrw_iteration_bind(qrw_handle h, const qrw_iteration_buffers *buffers);
+int qrw_iteration_step(qrw_handle h, int32_t k, const double *d_x_f_mpc, void *stream);
+
 /* ---------------- asynchronous MPC ----------------
  * The reference runs the MPC in a child process on its own CPU core and polls a shared flag
  * (scripts/MPC_Wrapper.py:150-298).  Here the MPC gets its own HIP stream restricted to a subset of the compute

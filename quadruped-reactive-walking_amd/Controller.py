@@ -134,13 +134,25 @@ class Controller_batch:
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
         loop = self._s_loop.torch
-        loop.wait_stream(caller)
-        # an iteration that does not solve is two library calls: given the loop's stream explicitly (no stream context to enter)
+        # a caller that already works on the loop's stream (`with torch.cuda.stream(ctl.loop_stream)`) needs no hand-over: the two
+        # stream waits below are four runtime calls, ~30 us of host time per iteration -- more than the iteration's two launches
+        on_loop = caller.cuda_stream == self._s_loop.ptr
+        if not on_loop:
+            loop.wait_stream(caller)
+        # an iteration that does not solve is one library call: given the loop's stream explicitly (no stream context to enter)
         if not (self.fused and (self.k % self.k_mpc) != 0 and self._nonsolve_fast(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, loop)):
             with torch.cuda.stream(loop):
                 self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
-        caller.wait_stream(loop)
+        if not on_loop:
+            caller.wait_stream(loop)
         return self.result
+
+    @property
+    def loop_stream(self):
+        """The stream the control loop's kernels run on in the asynchronous mode (a torch ExternalStream on the loop's compute
+        units), None otherwise.  A caller that produces the inputs and consumes the Result under `with torch.cuda.stream(
+        ctl.loop_stream)` saves compute() the hand-over between its own stream and this one."""
+        return self._s_loop.torch if self.multiprocessing else None
 
     def _solve_async(self, plan, k):
         """scripts/MPC_Wrapper.py:150-180 (run_MPC_asynchronous): hand the planner outputs to the MPC and return."""
@@ -254,16 +266,21 @@ class Controller_batch:
             self.x_f_mpc = self._mpc_default
 
     def _nonsolve_fast(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, stream):
-        """An iteration that does not solve, through the handle's pre-validated argument lists (qrw_hip.Batch.bind_iteration: the
-        same two launches as control_pre + wbc_compute_result).  False until both calls have run once the ordinary way."""
+        """An iteration that does not solve, through the buffers bound in the library (qrw_hip.Batch.bind_iteration: the same two
+        launches as control_pre + wbc_compute_result, one foreign call).  False until both calls have run once the ordinary way.
+        Bound again whenever the caller comes with other tensor objects than last time (a loop passes the same ones every tick)."""
         if self._pre is None or self._post is None or self.result is None:
             return False
         fast = self._fast
-        if fast is None or fast[0] is not self._pre or fast[1] is not self._post or fast[2] is not stream:
-            self._fast = fast = (self._pre, self._post, stream, self._b.bind_iteration(self._pre, self._post, stream))
+        if (fast is None or fast[1] is not self._pre or fast[2] is not self._post or fast[3] is not stream
+                or fast[4] is not joy_v_ref or fast[5] is not q_filt or fast[6] is not v_filt or fast[7] is not rpy
+                or fast[8] is not v_secu
+                or not (fast[9] is joystick_code or (isinstance(joystick_code, int) and fast[9] == joystick_code))):
+            step = self._b.bind_iteration(self._pre, self._post, (joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code), stream)
+            self._fast = fast = (step, self._pre, self._post, stream, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
         k = self.k
         self._pick_mpc_result(k)
-        fast[3](k, joy_v_ref, q_filt, v_filt, rpy, joystick_code, self.x_f_mpc, v_secu)
+        fast[0](k, self.x_f_mpc)
         self.k = k + 1
         return True
 
@@ -319,6 +336,7 @@ class Controller_groups(Controller_batch):
         self.stagger = bool(stagger)
         self._delay = [(g * int(k_mpc)) // G if self.stagger else 0 for g in range(G)]
         self._calls = [0] * G
+        self._views = None
         self._tick_ev = {}
         self.error_flag = torch.zeros((self.B,), dtype=torch.int32, device=self.dev)
         self.result = Result(self._fleet_result)
@@ -376,14 +394,24 @@ class Controller_groups(Controller_batch):
             self._tick_ev[t + 1] = ev
         return r
 
+    def _group_views(self, args):
+        """The groups' slices of the fleet-wide argument tensors, made once per set of tensor OBJECTS: a loop passes the same ones on
+        every tick, and the groups' bound iterations (Controller_batch._nonsolve_fast) recognise their inputs by identity."""
+        c = self._views
+        if c is None or len(c[0]) != len(args) or any(a is not b for a, b in zip(c[0], args)):
+            torch = self._torch
+            views = [tuple(a[sl] if torch.is_tensor(a) else a for a in args) for sl in self._sl]
+            self._views = c = (args, views)  # (holds the arguments: an id cannot be reused while it is cached)
+        return c[1]
+
     def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
-        for g, (sl, st) in enumerate(zip(self._sl, self.streams)):
+        views = self._group_views((joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code))
+        for g, st in enumerate(self.streams):
             st.wait_stream(caller)  # the inputs produced on the caller's stream are ready
-            code = joystick_code[sl] if torch.is_tensor(joystick_code) else joystick_code
             with torch.cuda.stream(st):
-                self.compute_group(g, joy_v_ref[sl], q_filt[sl], v_filt[sl], rpy[sl], v_secu[sl], code)
+                self.compute_group(g, *views[g])
         for st in self.streams:
             caller.wait_stream(st)
         return self.result

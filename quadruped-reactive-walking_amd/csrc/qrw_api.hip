@@ -80,6 +80,8 @@ struct qrw_handle_s {
   // Synchronisation is per handle, never device-wide: the *_host entry points and the getters run their copies and launches on
   // `host_stream` (private, non-blocking: it neither waits for nor stalls the legacy default stream or any other handle's
   // streams) and wait for exactly two things -- the last launch of the state family they read (wait_family) and their own copies.
+  qrw_iteration_buffers iter_bufs;  // qrw_iteration_bind
+  bool iter_bound = false;
   hipStream_t host_stream = nullptr;
   hipStream_t last_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   bool launched[4] = {false, false, false, false};
@@ -1317,4 +1319,31 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
   note_launch(h, kFamPlan, (hipStream_t)stream);
   note_launch(h, kFamCtrl, (hipStream_t)stream);
   return 0;
+}
+
+// ------------------------------------------------------------------ a non-solving iteration on bound buffers
+extern "C" int qrw_iteration_bind(qrw_handle h, const qrw_iteration_buffers* b) {
+  if (!h || !b) return fail(-1, "qrw_iteration_bind: null argument");
+  if (!h->plan_ready) return fail(-1, "qrw_iteration_bind: planner not initialised");
+  if (!b->d_joy_vref || !b->d_q_filt || !b->d_v_filt || !b->d_rpy || !b->d_v_secu || !b->d_q || !b->d_v || !b->d_hv || !b->d_vref ||
+      !b->d_xref || !b->d_feet_pva || !b->d_contacts || !b->d_q_wbc || !b->d_b_v || !b->d_f_cmd || !b->d_feet_cmd || !b->d_result)
+    return fail(-1, "qrw_iteration_bind: null buffer (only d_code, d_oRh_oTh, d_target, d_x_f_wbc and the WBC outputs other than "
+                    "d_result may be NULL)");
+  h->iter_bufs = *b;
+  h->iter_bound = true;
+  return 0;
+}
+
+extern "C" int qrw_iteration_step(qrw_handle h, int32_t k, const double* d_x_f_mpc, void* stream) {
+  if (!h || !d_x_f_mpc) return fail(-1, "qrw_iteration_step: null argument");
+  if (!h->iter_bound) return fail(-1, "qrw_iteration_step: no buffers bound (qrw_iteration_bind)");
+  const qrw_iteration_buffers& b = h->iter_bufs;
+  const size_t plane = (size_t)h->cfg.batch * 12;  // d_feet_cmd [3][B][3][4]: the planes are the WBC's pgoals / vgoals / agoals
+  int rc = qrw_control_pre(h, k, b.d_joy_vref, b.d_q_filt, b.d_v_filt, b.d_rpy, b.d_code, b.code_scalar, d_x_f_mpc, b.d_q, b.d_v, b.d_hv,
+                           b.d_vref, b.d_oRh_oTh, b.d_xref, nullptr, nullptr, b.d_target, b.d_feet_pva, b.d_contacts, b.d_x_f_wbc,
+                           b.d_q_wbc, b.d_b_v, b.d_f_cmd, b.d_feet_cmd, stream);
+  if (rc) return rc;
+  return qrw_wbc_compute_result(h, b.d_q_wbc, b.d_b_v, b.d_f_cmd, b.d_contacts, b.d_feet_cmd, b.d_feet_cmd + plane, b.d_feet_cmd + 2 * plane,
+                                b.d_tau_ff, b.d_qdes, b.d_vdes, b.d_f_with_delta, b.d_ddq_res, b.d_feet, b.d_q_filt, b.d_v_secu, b.d_result,
+                                b.d_error_flag, stream);
 }

@@ -28,6 +28,16 @@ class _PlannerConfig(C.Structure):
                 ("lock_time", C.c_double), ("init_target", C.c_double * 12), ("init_foot_pos", C.c_double * 12)]
 
 
+class _IterationBuffers(C.Structure):
+    """qrw_iteration_buffers (include/qrw_hip.h), field for field."""
+    _fields_ = ([(n, C.c_void_p) for n in ("d_joy_vref", "d_q_filt", "d_v_filt", "d_rpy", "d_v_secu", "d_code")]
+                + [("code_scalar", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("d_q", "d_v", "d_hv", "d_vref", "d_oRh_oTh", "d_xref", "d_target", "d_feet_pva",
+                                              "d_contacts", "d_x_f_wbc", "d_q_wbc", "d_b_v", "d_f_cmd", "d_feet_cmd",
+                                              "d_tau_ff", "d_qdes", "d_vdes", "d_f_with_delta", "d_ddq_res", "d_feet", "d_result",
+                                              "d_error_flag")])
+
+
 PLAN_GAIT, PLAN_FOOTSTEPS, PLAN_TRAJ, PLAN_STATE, PLAN_OUTPUTS = 2, 4, 8, 16, 32
 SHOULDERS = np.array([[0.1946, 0.1946, -0.1946, -0.1946], [0.14695, -0.14695, 0.14695, -0.14695], [0.0, 0.0, 0.0, 0.0]])
 
@@ -74,6 +84,8 @@ SIGNATURES = {
     "qrw_mpc_result_shift": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qrw_control_pre": (C.c_int, [_vp, C.c_int32] + [_vp] * 4 + [_vp, C.c_int32, _vp] + [_vp] * 16 + [_vp]),
     "qrw_wbc_compute_result": (C.c_int, [_vp] + [_vp] * 13 + [_vp] * 4 + [_vp]),
+    "qrw_iteration_bind": (C.c_int, [_vp, C.POINTER(_IterationBuffers)]),
+    "qrw_iteration_step": (C.c_int, [_vp, C.c_int32, _vp, _vp]),
     "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "qrw_stream_destroy": (C.c_int, [_vp]),
     "qrw_device_cu_count": (C.c_int, [C.c_int32, _ip]),
@@ -535,43 +547,52 @@ class Batch:
             self._stream()), "qrw_wbc_compute_result")
         return out
 
-    def bind_iteration(self, pre, post, stream=None):
-        """control_pre (an iteration that does not solve: no MPC inputs) + wbc_compute_result on FIXED output buffers -- the dicts
-        those two calls returned -- as one callable with the 34 output / hand-over pointers validated once: a control loop
-        passes the same buffers every iteration, and validating them again was most of compute()'s 40 us of host time.
-        step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu): the per-call tensors are validated as always.
+    def bind_iteration(self, pre, post, inputs, stream=None):
+        """An iteration that does not solve (control_pre without MPC inputs + wbc_compute_result) on FIXED buffers as one callable:
+        `pre` / `post` are the dicts those two calls returned, `inputs` = (joy_v_ref, q_filt, v_filt, rpy, v_secu, code) the loop's
+        input tensors (code: int or CUDA int32 (B,)).  Everything is validated ONCE and bound in the library (qrw_iteration_bind);
+        step(k, x_f_mpc) then is one foreign call with three arguments (qrw_iteration_step: the two launches) -- a control loop
+        passes the same buffers on every tick, and marshalling their ~50 pointers again was most of compute()'s host time.
         stream: a torch stream to launch on whatever the current stream is (None: the caller's current stream, looked up per call)."""
         import torch
 
         B, N = self.B, self.N
-        d, null = self._dev, _vp(0)
-        pre_ptrs = (d(pre["q"], (B, 19)), d(pre["v"], (B, 18)), d(pre["h_v"], (B, 6)), d(pre["v_ref"], (B, 6)),
-                    d(pre["oRh_oTh"], (B, 12)), d(pre["xref"], (B, 12, N + 1)), null, null, d(pre["target"], (B, 3, 4)),
-                    d(pre["feet_pva"], (B, 3, 3, 4)), d(pre["contacts"], (B, 4)), d(pre["x_f_wbc"], (B, 24)),
-                    d(pre["q_wbc"], (B, 19)), d(pre["b_v"], (B, 18)), d(pre["f_cmd"], (B, 12)), d(pre["feet_cmd"], (3, B, 3, 4)))
-        fc = pre["feet_cmd"]
-        post_a = (d(pre["q_wbc"], (B, 19)), d(pre["b_v"], (B, 18)), d(pre["f_cmd"], (B, 12)), d(pre["contacts"], (B, 4)),
-                  d(fc[0], (B, 3, 4)), d(fc[1], (B, 3, 4)), d(fc[2], (B, 3, 4)), d(post["tau_ff"], (B, 12)), d(post["qdes"], (B, 19)),
-                  d(post["vdes"], (B, 18)), d(post["f_with_delta"], (B, 12)), d(post["ddq_res"], (B, 6)), d(post["feet"], (B, 3, 3, 4)))
+        d = self._dev
+        joy_v_ref, q_filt, v_filt, rpy, v_secu, code = inputs
         ef = post["error_flag"]
         if not (ef.is_cuda and ef.dtype == torch.int32 and ef.is_contiguous() and tuple(ef.shape) == (B,)):
             raise QrwError("error_flag: expected a contiguous int32 CUDA tensor of shape (B,)")
-        post_b = (d(post["result"], (B, 5, 12)), _vp(ef.data_ptr()))
-        keep = (pre, post, fc)  # the buffers stay alive as long as the callable does
-        f_pre, f_post, h, cur_stream = self._lib.qrw_control_pre, self._lib.qrw_wbc_compute_result, self._handle, self._stream
+        b = _IterationBuffers()
+        b.d_joy_vref, b.d_q_filt, b.d_v_filt = d(joy_v_ref, (B, 6)), d(q_filt, (B, 19)), d(v_filt, (B, 18))
+        b.d_rpy, b.d_v_secu = d(rpy, (B, 3)), d(v_secu, (B, 12))
+        if isinstance(code, torch.Tensor):
+            if not (code.is_cuda and code.dtype == torch.int32 and code.is_contiguous() and tuple(code.shape) == (B,)):
+                raise QrwError("joystick code: expected a contiguous int32 CUDA tensor of shape (B,)")
+            b.d_code, b.code_scalar = code.data_ptr(), 0
+        else:
+            b.d_code, b.code_scalar = None, int(code)
+        for name, shape in (("q", (B, 19)), ("v", (B, 18)), ("hv", (B, 6)), ("vref", (B, 6)), ("oRh_oTh", (B, 12)),
+                            ("xref", (B, 12, N + 1)), ("target", (B, 3, 4)), ("feet_pva", (B, 3, 3, 4)), ("contacts", (B, 4)),
+                            ("x_f_wbc", (B, 24)), ("q_wbc", (B, 19)), ("b_v", (B, 18)), ("f_cmd", (B, 12)),
+                            ("feet_cmd", (3, B, 3, 4))):
+            setattr(b, "d_" + name, d(pre[{"hv": "h_v", "vref": "v_ref"}.get(name, name)], shape))
+        for name, shape in (("tau_ff", (B, 12)), ("qdes", (B, 19)), ("vdes", (B, 18)), ("f_with_delta", (B, 12)),
+                            ("ddq_res", (B, 6)), ("feet", (B, 3, 3, 4)), ("result", (B, 5, 12))):
+            setattr(b, "d_" + name, d(post[name], shape))
+        b.d_error_flag = ef.data_ptr()
+        _check(self._lib.qrw_iteration_bind(self._handle, C.byref(b)), "qrw_iteration_bind")
+        keep = (pre, post, inputs)  # the buffers stay alive as long as the callable does
+        f_step, h, cur_stream = self._lib.qrw_iteration_step, self._handle, self._stream
         fixed = None if stream is None else _vp(stream.cuda_stream)
+        last = [None, None]  # the MPC result tensor validated last, and its pointer (the loop alternates between a few buffers)
 
-        def step(k, joy_v_ref, q_filt, v_filt, rpy, code, x_f_mpc, v_secu):
+        def step(k, x_f_mpc):
             _ = keep
-            st = cur_stream() if fixed is None else fixed
-            if isinstance(code, torch.Tensor):
-                cptr, cs = _vp(code.data_ptr()), 0
-            else:
-                cptr, cs = null, int(code)
-            qf = d(q_filt, (B, 19))
-            _check(f_pre(h, int(k), d(joy_v_ref, (B, 6)), qf, d(v_filt, (B, 18)), d(rpy, (B, 3)), cptr, cs,
-                         d(x_f_mpc, (B, 24, N)), *pre_ptrs, st), "qrw_control_pre")
-            _check(f_post(h, *post_a, qf, d(v_secu, (B, 12)), *post_b, st), "qrw_wbc_compute_result")
+            if x_f_mpc is not last[0]:
+                last[0], last[1] = x_f_mpc, d(x_f_mpc, (B, 24, N))
+            rc = f_step(h, k, last[1], cur_stream() if fixed is None else fixed)
+            if rc:
+                _check(rc, "qrw_iteration_step")
 
         return step
 
