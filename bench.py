@@ -396,9 +396,13 @@ def main():
             out["config4_n32_mixed"] = config_leg(4096, 32, ("walk", "trot", "bounding"), dev, W=3, K=6, closed=True, groups=2,
                                                   acc=(128, 6), threads=thr)
         if not args.no_cpu_baseline:
-            base, ref_out = cpu_baseline(synth, args.cpu_sample, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
+            # bounded sample: --cpu-sample instances are sized for the 16 host cores a 1-GPU box usually owns (~25 s of CPU work);
+            # a box that gives this process fewer cores gets proportionally fewer instances, so the leg's wall time stays put
+            cores = max(1, min(int(args.cpu_threads), len(os.sched_getaffinity(0))))
+            Bc = max(32, min(args.cpu_sample, (args.cpu_sample * cores + 15) // 16))
+            base, ref_out = cpu_baseline(synth, Bc, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
             out["cpu_baseline"] = base
-            out["accuracy"] = accuracy_vs_oracle(synth, ref_out, args.cpu_sample, N, N_gait, gaits, args.cpu_steps, dev)
+            out["accuracy"] = accuracy_vs_oracle(synth, ref_out, Bc, N, N_gait, gaits, args.cpu_steps, dev)
             out["torque_max_abs_err"] = out["accuracy"]["torque_max_abs_err"]
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -525,6 +529,8 @@ def leg_accuracy(Bc, steps, N, N_gait, gaits, mpc_only, dev, threads):
     import oracle
     oracle.build(fast=True)
     cores = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+    if cores < 8 and Bc > 16:  # a box that gives this process few host cores: a smaller sample, the same wall time
+        Bc = max(16, (Bc * cores + 7) // 8)
     sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps)
     eng = qrw_hip.Batch(Bc, n_steps=N, N_gait=N_gait, dt_mpc=0.02, T_gait=0.02 * N, dt_wbc=0.002, device=dev.index or 0)
     mpc = oracle.MPCBatch(Bc, 0.02, N, 0.02 * N, N_gait, fast=True)

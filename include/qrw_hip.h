@@ -320,6 +320,11 @@ int qrw_stream_create(int32_t device, int32_t first_cu, int32_t n_cus, void **st
 int qrw_stream_destroy(void *stream);
 /* number of compute units of the device (256 on MI355X) */
 int qrw_device_cu_count(int32_t device, int32_t *n_cus);
+/* Stream hand-over without host synchronisation: everything enqueued on `waiter` after this call runs after what is on `signaller`
+ * now (hipEventRecord on `signaller` + hipStreamWaitEvent on `waiter`, with an event the handle keeps: two runtime calls, where
+ * torch's Stream.wait_stream creates and destroys an event object each time -- ~12 us, and a joined stream-group iteration needs
+ * several).  Plumbing of the stream-group / asynchronous modes; no reference counterpart (a child process and flags there). */
+int qrw_stream_wait_stream(qrw_handle h, void *waiter, void *signaller);
 
 /* Diagnostic: checks on the device what the MPC solver's linear algebra relies on — the row_newbcast form of
  * v_fmac_f64, the twisted block sweeps in the production LDS layout and the in-register Gauss-Jordan inverse

@@ -138,13 +138,13 @@ class Controller_batch:
         # stream waits below are four runtime calls, ~30 us of host time per iteration -- more than the iteration's two launches
         on_loop = caller.cuda_stream == self._s_loop.ptr
         if not on_loop:
-            loop.wait_stream(caller)
+            self._b.stream_wait_stream(loop, caller)
         # an iteration that does not solve is one library call: given the loop's stream explicitly (no stream context to enter)
         if not (self.fused and (self.k % self.k_mpc) != 0 and self._nonsolve_fast(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, loop)):
             with torch.cuda.stream(loop):
                 self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
         if not on_loop:
-            caller.wait_stream(loop)
+            self._b.stream_wait_stream(caller, loop)
         return self.result
 
     @property
@@ -404,16 +404,34 @@ class Controller_groups(Controller_batch):
             self._views = c = (args, views)  # (holds the arguments: an id cannot be reused while it is cached)
         return c[1]
 
+    def _solves_now(self, g):
+        """Will group g's next compute_group call carry an MPC solve (its robots' own clock at a multiple of k_mpc)?"""
+        return self._calls[g] >= self._delay[g] and (self.groups[g].k % self.k_mpc) == 0
+
     def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
+        """One fleet tick: whole-fleet inputs in, whole-fleet Result out, valid on the caller's stream.  A group whose iteration
+        does not solve runs on the caller's stream itself (nothing to overlap: two launches of ~25 us); a group whose iteration
+        carries its MPC solve runs on the group's stream, forked from and joined to the caller's stream -- with staggered groups
+        (the default from 2048 robots on) that is one group on two ticks out of k_mpc, and the fleet's worst tick takes a
+        half-fleet solve instead of the whole fleet's."""
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
         views = self._group_views((joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code))
-        for g, st in enumerate(self.streams):
-            st.wait_stream(caller)  # the inputs produced on the caller's stream are ready
+        if self.multiprocessing:
+            forked = list(range(self.G))  # (asynchronous groups bring their own compute-unit-masked streams)
+        else:
+            forked = [g for g in range(self.G) if self._solves_now(g)]
+            for g in range(self.G):
+                if g not in forked:
+                    self.compute_group(g, *views[g])
+        b0 = self.groups[0]._b
+        for g in forked:
+            st = self.streams[g]
+            b0.stream_wait_stream(st, caller)  # the inputs produced on the caller's stream (and this tick's other groups) are ready
             with torch.cuda.stream(st):
                 self.compute_group(g, *views[g])
-        for st in self.streams:
-            caller.wait_stream(st)
+        for g in forked:
+            b0.stream_wait_stream(caller, self.streams[g])
         return self.result
 
     def stop_parallel_loop(self):

@@ -80,6 +80,7 @@ struct qrw_handle_s {
   // Synchronisation is per handle, never device-wide: the *_host entry points and the getters run their copies and launches on
   // `host_stream` (private, non-blocking: it neither waits for nor stalls the legacy default stream or any other handle's
   // streams) and wait for exactly two things -- the last launch of the state family they read (wait_family) and their own copies.
+  hipEvent_t order_ev = nullptr;     // qrw_stream_wait_stream (created on first use)
   qrw_iteration_buffers iter_bufs;  // qrw_iteration_bind
   bool iter_bound = false;
   hipStream_t host_stream = nullptr;
@@ -453,6 +454,7 @@ extern "C" int qrw_destroy(qrw_handle h) {
   if (h->pre_err_host) hipHostFree(h->pre_err_host);
   hipFree(h->stage); hipFree(h->stage_i);
   if (h->host_stream) hipStreamDestroy(h->host_stream);
+  if (h->order_ev) hipEventDestroy(h->order_ev);
   delete h;
   return 0;
 }
@@ -1281,6 +1283,17 @@ extern "C" int qrw_stream_destroy(void* stream) {
   }
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   return e == hipSuccess ? 0 : fail(-10, "qrw_stream_destroy: hipStreamDestroy failed", e);
+}
+
+extern "C" int qrw_stream_wait_stream(qrw_handle h, void* waiter, void* signaller) {
+  if (!h) return fail(-1, "qrw_stream_wait_stream: null handle");
+  if (waiter == signaller) return 0;
+  DeviceScope dev_scope__(h->cfg.device);
+  if (!h->order_ev) HIP_OK(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming), "qrw_stream_wait_stream: hipEventCreate");
+  // one event serves every hand-over: hipStreamWaitEvent captures the record that is current when it is called
+  HIP_OK(hipEventRecord(h->order_ev, (hipStream_t)signaller), "qrw_stream_wait_stream: hipEventRecord");
+  HIP_OK(hipStreamWaitEvent((hipStream_t)waiter, h->order_ev, 0), "qrw_stream_wait_stream: hipStreamWaitEvent");
+  return 0;
 }
 
 // ------------------------------------------------------------------ fused head of a control iteration

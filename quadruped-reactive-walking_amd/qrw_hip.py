@@ -89,6 +89,7 @@ SIGNATURES = {
     "qrw_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "qrw_stream_destroy": (C.c_int, [_vp]),
     "qrw_device_cu_count": (C.c_int, [C.c_int32, _ip]),
+    "qrw_stream_wait_stream": (C.c_int, [_vp, _vp, _vp]),
     "qrw_selftest_sweeps": (C.c_int, [_dp]),
     "qrw_state_bytes": (C.c_int64, [_vp]),
 }
@@ -265,6 +266,11 @@ class Batch:
             self._dev(out["ddq_res"], (B, 6)), self._dev(out["feet"], (B, 3, 3, 4)), self._stream()),
             "qrw_wbc_compute")
         return out
+
+    def stream_wait_stream(self, waiter, signaller):
+        """`waiter` (a torch stream) waits for what is on `signaller` now; no host synchronisation (qrw_stream_wait_stream)."""
+        _check(self._lib.qrw_stream_wait_stream(self._handle, _vp(waiter.cuda_stream), _vp(signaller.cuda_stream)),
+               "qrw_stream_wait_stream")
 
     def wbc_set_lanes(self, lanes):
         """Lanes per robot instance of the full WBC step: 16 (default, whole-chip streams) or 4 (streams that own few compute

@@ -675,3 +675,28 @@ def test_time_sliced_launch_edge_cases(synth_mod, monkeypatch):
             assert (sb_["status"] != -100).sum() == B - len(range(5, B, 97))  # the un-set-up ones stay so (reference: a null workspace)
     masked.close()
     rest.close()
+
+
+@pytest.mark.parametrize("N", [16, 8, 32])
+def test_full_gait_table_without_a_zero_row(oracle_mod, synth_mod, N):
+    """N_gait == n_steps with every horizon step planned: no zero row ends the table, where the reference's construct_gait runs
+    one row past its matrix (/root/reference/src/MPC.cpp:686-701, undefined behaviour).  Kernel and oracle stop at the table's end
+    (the oracle's one deliberate departure): HIP against the oracle on the full table, and bit-equal to the HIP path
+    fed the same rows followed by zero rows in a larger table -- the form that is defined in the reference."""
+    import qrw_hip
+
+    eng, refs, worst = run_sequence(oracle_mod, synth_mod, 4, N, ("trot", "walk"), 4, 5000, closed_loop=False, N_gait=N)
+    assert worst < 1e-6
+    padded = synth_mod.SyntheticBatch(4, N, N_gait=N + 4, gaits=("trot", "walk"), seed0=5000)
+    full = synth_mod.SyntheticBatch(4, N, N_gait=N, gaits=("trot", "walk"), seed0=5000)
+    a = qrw_hip.Batch(4, n_steps=N, N_gait=N, T_gait=0.02 * N)
+    b = qrw_hip.Batch(4, n_steps=N, N_gait=N + 4, T_gait=0.02 * N)
+    for s in range(4):
+        da, db = full.step(s), padded.step(s)
+        assert (np.abs(da["fsteps"]).sum(axis=2) > 0).all()
+        oa, ob = a.mpc_solve_host(da["xref"], da["fsteps"], s), b.mpc_solve_host(db["xref"], db["fsteps"], s)
+        assert np.array_equal(oa, ob), s
+        assert np.array_equal(a.mpc_stats()["iters"], b.mpc_stats()["iters"])
+    ga, Sa = a.mpc_gait(0)
+    gb, Sb = b.mpc_gait(0)
+    assert np.array_equal(ga, gb[:N]) and np.array_equal(Sa, Sb) and np.array_equal(ga, refs[0].get_gait())

@@ -370,3 +370,27 @@ def test_twostance_monodromy_explains_the_red_known_answer(oracle_mod, monkeypat
     x_f, xref = trot_kat.run_twostance(solve_fixed, 400, centered=False)
     assert set(statuses) == {1}
     assert np.allclose(x_f[:12, 0], xref[:, 1], atol=1e-2), np.abs(x_f[:12, 0] - xref[:, 1]).max()  # scripts/test_mpc.py:190
+
+
+def test_full_gait_table_without_a_zero_row_is_defined_behaviour(oracle_mod, synth_mod):
+    """The oracle's ONE deliberate departure from the reference (DESIGN.md 2): `MPC::construct_gait` walks `fsteps` until its first
+    all-zero row and then writes a zero row at that index (/root/reference/src/MPC.cpp:686-701) -- with N_gait == n_steps and
+    every horizon step planned the table has no zero row, and the reference reads row N_gait of an N_gait-row matrix and writes
+    `gait.row(N_gait)`: undefined behaviour there (Eigen without bounds checks).  Oracle and HIP kernel stop at the table's end.
+    The agreed behaviour, pinned here: a full table gives exactly the result of the same rows followed by zero rows in a larger
+    table (which IS defined in the reference), gait matrix and iteration counts included."""
+    for N in (16, 8):
+        full = synth_mod.SyntheticBatch(2, N, N_gait=N, gaits=("trot", "walk"), seed0=5000)
+        padded = synth_mod.SyntheticBatch(2, N, N_gait=N + 4, gaits=("trot", "walk"), seed0=5000)
+        ma = [oracle_mod.MPC(0.02, N, 0.02 * N, N) for _ in range(2)]
+        mb = [oracle_mod.MPC(0.02, N, 0.02 * N, N + 4) for _ in range(2)]
+        for s in range(3):
+            da, db = full.step(s), padded.step(s)
+            assert np.array_equal(da["fsteps"], db["fsteps"][:, :N]) and not db["fsteps"][:, N:].any()
+            assert (np.abs(da["fsteps"]).sum(axis=2) > 0).all()  # the full table really has no zero row
+            for b in range(2):
+                assert ma[b].run(s, da["xref"][b], da["fsteps"][b]) == 0 and mb[b].run(s, db["xref"][b], db["fsteps"][b]) == 0
+                assert np.array_equal(ma[b].get_latest_result(), mb[b].get_latest_result()), (N, s, b)
+                assert ma[b].iter == mb[b].iter and ma[b].status == mb[b].status == 1
+                assert np.array_equal(ma[b].get_gait(), mb[b].get_gait()[:N])
+                assert np.array_equal(ma[b].get_Sgait(), mb[b].get_Sgait())
