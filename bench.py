@@ -31,11 +31,9 @@ sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd")]
 # process uses more than four over its legs, and two stream groups that land on one queue serialise (DESIGN.md 4.1:
 # 600 k instead of 970 k steps/s).  Read by the runtime at its first call: set before anything touches the GPU.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# the CPU baseline's OpenMP threads (oracle/) stay on the cores they start on: read by libgomp when it initialises, i.e. at the
-# first import that pulls it in (torch) -- hence here.  cpu_baseline reports it as "pinned".
-if os.environ.get("WORLD_SIZE", "1") == "1":  # (only the single-process run times the CPU baseline; ranks of a multi-GPU job would
-    os.environ.setdefault("OMP_PROC_BIND", "close")  # all bind to the same first cores)
-    os.environ.setdefault("OMP_PLACES", "cores")
+# the host cores this process may use, read before any import that starts an OpenMP runtime (a runtime told to bind its threads
+# narrows the initial thread's mask, and with it what sched_getaffinity reports later)
+ALLOWED_CPUS = len(os.sched_getaffinity(0))
 
 import numpy as np  # noqa: E402
 
@@ -398,7 +396,7 @@ def main():
         if not args.no_cpu_baseline:
             # bounded sample: --cpu-sample instances are sized for the 16 host cores a 1-GPU box usually owns (~25 s of CPU work);
             # a box that gives this process fewer cores gets proportionally fewer instances, so the leg's wall time stays put
-            cores = max(1, min(int(args.cpu_threads), len(os.sched_getaffinity(0))))
+            cores = max(1, min(int(args.cpu_threads), ALLOWED_CPUS))
             Bc = max(32, min(args.cpu_sample, (args.cpu_sample * cores + 15) // 16))
             base, ref_out = cpu_baseline(synth, Bc, N, N_gait, gaits, args.cpu_threads, args.cpu_steps)
             out["cpu_baseline"] = base
@@ -528,7 +526,7 @@ def leg_accuracy(Bc, steps, N, N_gait, gaits, mpc_only, dev, threads):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build(fast=True)
-    cores = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+    cores = max(1, min(int(threads), ALLOWED_CPUS))
     if cores < 8 and Bc > 16:  # a box that gives this process few host cores: a smaller sample, the same wall time
         Bc = max(16, (Bc * cores + 7) // 8)
     sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps)
@@ -976,7 +974,7 @@ def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 4096)):
 
 def host_cpu_info():
     """What the CPU baseline ran on: model name, logical CPUs of the box and of this process, clocks from /proc/cpuinfo."""
-    info = {"model": None, "logical_cpus": os.cpu_count(), "cpus_allowed": len(os.sched_getaffinity(0)), "mhz_now_max": None,
+    info = {"model": None, "logical_cpus": os.cpu_count(), "cpus_allowed": ALLOWED_CPUS, "mhz_now_max": None,
             "mhz_max": None}
     try:
         mhz = []
@@ -1001,8 +999,10 @@ def host_cpu_info():
 
 
 def omp_pinned():
-    """True when the OpenMP runtime was told to bind the oracle's threads to places (OMP_PROC_BIND, set at the top of this
-    file unless the caller's environment says otherwise)."""
+    """True when the OpenMP runtime was told to bind the oracle's threads to places (OMP_PROC_BIND in the caller's environment).
+    bench.py does not set it: binding also narrows the initial thread's CPU mask, which every helper thread of the process --
+    the HIP runtime's included -- inherits; measured once by accident, the CPU leg then ran on the 2 hardware threads of one
+    core.  Unpinned threads on a shared host are part of the round-to-round spread of this figure."""
     v = os.environ.get("OMP_PROC_BIND", "").lower()
     return v not in ("", "false", "0")
 
@@ -1015,7 +1015,7 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build(fast=True)
-    cores = max(1, min(int(threads), len(os.sched_getaffinity(0))))
+    cores = max(1, min(int(threads), ALLOWED_CPUS))
     sb = synth.SyntheticBatch(Bc, N, N_gait=N_gait, gaits=gaits, n_seq=steps + 1)
     mpc = oracle.MPCBatch(Bc, 0.02, N, 0.02 * N, N_gait, fast=True)
     wbc = oracle.WbcBatch(Bc, 0.002, fast=True)
