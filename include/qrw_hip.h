@@ -72,10 +72,12 @@ const char *qrw_last_error(void);
  *   d_out      [B][24][N]     x_f_applied: rows 0-11 predicted states, 12-23 forces
  * Scheduling inside the call (no reference counterpart; never visible in the results): instances are started longest first by
  * a moving average of their previous iteration counts; at N > 16 with more instances than the device holds at a time, a
- * workgroup runs at most 600 ADMM iterations of a solve, then parks it (bit-exact resume) and the parked solves are taken
- * longest-predicted-remainder first, the prediction read off the decay of the residuals.  d_out is pre-filled with NaN then:
- * should the launch's queue ever give up (a workgroup waits 2 s for a parked solve without any slice of the launch ending --
- * never expected; it rests on workgroups of one launch starting in index order), the unfinished instances keep NaN, the kernel
+ * workgroup runs at most 600 ADMM iterations of a solve, then parks it (bit-exact resume) for one of the launch's taker
+ * workgroups if one is still to come -- it goes on itself otherwise -- and the parked solves are taken
+ * longest-predicted-remainder first, the prediction read off the decay of the residuals.  No workgroup waits for work that a
+ * workgroup not yet running would have to produce (since round 5; a taker that finds nothing parked leaves).  d_out is
+ * pre-filled with NaN then: should a parked solve not reach its taker (a queue overrun, or the few instructions between a
+ * parker's reservation and its store taking 2 s -- never expected), the unfinished instances keep NaN, the kernel
  * leaves a code in a host-mapped word, and THE NEXT qrw_mpc_solve of the handle returns -12 once, without launching (no device
  * sync involved; qrw_mpc_get_stats reports it as well).  The call after that runs normally and starts the unfinished instances
  * cold (zero x, z, y, rho 0.1: what OSQP's store_solution leaves after a failed solve).  NaN forces stop the robot through the
@@ -131,7 +133,7 @@ int qrw_mpc_get_order(qrw_handle h, int32_t *h_order, float *h_ema, int32_t *has
 
 /* Diagnostic: bookkeeping of the last time-sliced qrw_mpc_solve (N > 16 with more instances than resident slots; all zero
  * otherwise): priority levels and slice length in use, solves parked into each level (level 0 = first parks), taker
- * workgroups that drew a ticket, instances counted as finished.  No reference counterpart. */
+ * workgroups that took a parked solve, instances counted as finished.  No reference counterpart. */
 int qrw_mpc_get_slice_stats(qrw_handle h, int32_t *levels, int32_t *chunk, uint32_t *h_parks_per_level /* [9] */,
                             uint32_t *h_takers, uint32_t *h_finished);
 

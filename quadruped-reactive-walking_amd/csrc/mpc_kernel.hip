@@ -523,77 +523,81 @@ __device__ __forceinline__ void seq_finish_task(const MpcArgs& a, int b, int seq
 // left for the end costs more than all the ordering gains); from the second park on its level is 1 + (levels - 2 -
 // predicted remaining / pre_bin), most remaining first, re-predicted at every park.  A workgroup takes from the lowest-numbered
 // level that has a solve: longest-remaining-first on 200-iteration bins, 1.03 x in the simulation (scripts/pre_priority_sim.py).
-//   Queues: pre_queue[level][slot]; per level a head (next slot to take) and a tail (next slot to fill).  A taker first draws
-// a TICKET T and waits until more than T solves have been parked in total (`parks`): from then on a solve is there for it --
-// tickets are drawn by resident workgroups only, every ticket below `parks` belongs to a workgroup that takes exactly one
-// solve, and a level's tail is advanced before `parks` -- so it pops with compare-and-swap from the best non-empty level and
-// simply looks again when another gated taker was faster (nobody polls a head: takers wait on `parks` alone, and only at the
-// end of the launch, when the queues are empty).  No deadlock: a waiting taker waits for a park that a RUNNING slice makes; if
-// every resident workgroup waited there would be no parked solve left (each has its ticket's taker) and none running, i.e. all
-// have finished, which the takers see (`finished` == B) and leave.
+//   Queues: pre_queue[level][slot]; per level a head (next slot to take) and a tail (next slot to fill).
+//   NOBODY WAITS FOR WORK THAT A NOT-YET-RUNNING WORKGROUP WOULD HAVE TO PRODUCE (round 5; rounds 3-4 gated the takers with
+// tickets and let them spin until a running slice parked: up to a slice's length, with a 2 s give-up clock -- outside the
+// forward-progress guarantees of the programming model).  The B * (pre_cmax - 1) taker workgroups are a BUDGET, `claims` counts
+// how many of them are spoken for:
+//   * a slice that reaches its end asks for a taker (`claims`++ < budget): granted -> it parks its solve and queues it, and its
+//     own exit frees the slot the next taker starts on; refused -> it simply goes on with the next slice itself, in place,
+//     without the set-up a resumed slice repeats;
+//   * a taker that finds every level empty gives itself up (`claims`++ < budget -> it leaves; the launch's last phase, when all
+//     unfinished solves are running and nothing is left to take); if THAT is refused, all the budget is spoken for, so exactly
+//     as many solves are (about to be) queued as takers are left, one of them for this workgroup: it polls the levels for the
+//     microseconds between a parker's claim and its store (the only wait left, on a RUNNING workgroup's next few instructions;
+//     the give-up clock guards it all the same).
+// Takers start after every index-dealt workgroup has (workgroups start in index order), i.e. when most first slices have ended
+// and the levels are full; the levels run empty only when the unfinished solves fit the resident slots -- from where on parking
+// would buy nothing.  If workgroups ever started in another order, takers would leave early and later slices continue in place:
+// slower, never wrong, never stuck.  A batch that is resident all at once (the known-answer gate, the tests' small batches)
+// would see every taker leave before the first park: its takers are launched as a grid of their own behind the index-dealt one
+// (mpc_preemptive_launch), so the park / resume path is exercised deterministically.
 //   pre_ctr words: qrw_kernels.h (kPre*Word)
-constexpr int kPreHead = kPreTicketWord, kPreTail = kPreParksWord, kPreDone = kPreDoneWord, kPreErr = kPreErrWord, kPreProgress = kPreProgressWord;
-// error word of the time-sliced launch (1, 3, 4: a taker gave up waiting; 2: a level's queue overran; 9: set by the host before
-// the launch, tests only: every queue-fed workgroup leaves at once).  mpc_pre_error_flush copies it to a host-mapped word behind
+constexpr int kPreTaken = kPreTicketWord, kPreParks = kPreParksWord, kPreDone = kPreDoneWord, kPreErr = kPreErrWord, kPreProgress = kPreProgressWord,
+              kPreClaims = kPreClaimsWord;
+// error word of the time-sliced launch (3, 4: the solve reserved for a taker did not arrive; 2: a level's queue overran; 9: set by
+// the host before the launch, tests only: every taker leaves at once).  mpc_pre_error_flush copies it to a host-mapped word behind
 // the launch (a store to host memory from inside this kernel, cold as it is, cost the N = 32 instantiation 1 % -- A/B in round 4)
 __device__ __forceinline__ void pre_set_error(const MpcArgs& a, unsigned code) {
   __hip_atomic_store(&a.pre_ctr[kPreErr], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one unit of the taker budget (tid 0): true = granted
+__device__ __forceinline__ bool pre_claim(const MpcArgs& a) {
+  return __hip_atomic_fetch_add(&a.pre_ctr[kPreClaims], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.pre_cap;
+}
 template <int NW>
 __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long long* sh, int tid) {
   int task = -1;
-  if (tid == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(&a.pre_ctr[kPreHead], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket < (unsigned)a.pre_cap) {
-      SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
-      bool gated = false;
-      for (;;) {
-        if (q_load(&a.pre_ctr[kPreTail]) > ticket) { gated = true; break; }
-        if (q_load(&a.pre_ctr[kPreDone]) >= (unsigned)a.B) break;  // every instance has finished: nothing will be parked any more
-        if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;               // somebody gave up already: do not wait another 2 s each
-        __builtin_amdgcn_s_sleep(32);
-        if (clock.expired()) {  // 2 s without any chunk of the launch ending: give up, loudly
-          pre_set_error(a, 1u);
-          break;
-        }
-      }
-      if (gated) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int* q = nullptr;
-        while (!q) {
-          for (int l = 0; l < a.pre_levels && !q; l++) {
-            unsigned* head = &a.pre_ctr[kPreLevelWord + 2 * l];
-            unsigned h = q_load(head);
-            while (h < q_load(head + 1)) {
-              if (__hip_atomic_compare_exchange_strong(head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                q = a.pre_queue + (size_t)l * a.pre_cap + h;
-                break;
-              }
-            }
-          }
-          if (!q) {  // another gated taker was faster on what this one saw: its own solve is (about to be) in some level
-            __builtin_amdgcn_s_sleep(8);
-            if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;
-            if (clock.expired()) {
-              pre_set_error(a, 3u);
-              break;
-            }
-          }
-        }
-        while (q) {  // the slot's store follows its reservation closely
-          task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (task >= 0) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (clock.expired()) {
-            pre_set_error(a, 4u);
+  if (tid == 0 && q_load(&a.pre_ctr[kPreErr]) == 0u) {
+    SeqGiveUp clock(&a.pre_ctr[kPreProgress]);
+    const int* q = nullptr;
+    bool owed = false;  // the budget is spoken for and this workgroup is still here: a parked solve is (about to be) queued for it
+    for (;;) {
+      for (int l = 0; l < a.pre_levels && !q; l++) {
+        unsigned* head = &a.pre_ctr[kPreLevelWord + 2 * l];
+        unsigned h = q_load(head);
+        while (h < q_load(head + 1)) {
+          if (__hip_atomic_compare_exchange_strong(head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            q = a.pre_queue + (size_t)l * a.pre_cap + h;
             break;
           }
         }
       }
-      if (task >= 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (q) break;
+      if (!owed) {
+        if (pre_claim(a)) break;  // nothing to take and nothing promised: leave
+        owed = true;
       }
+      __builtin_amdgcn_s_sleep(8);
+      if (q_load(&a.pre_ctr[kPreErr]) != 0u) break;
+      if (clock.expired()) {
+        pre_set_error(a, 3u);
+        break;
+      }
+    }
+    while (q) {  // the slot's store follows its reservation closely
+      task = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (task >= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (clock.expired()) {
+        pre_set_error(a, 4u);
+        break;
+      }
+    }
+    if (task >= 0) {
+      __hip_atomic_fetch_add(&a.pre_ctr[kPreTaken], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   if constexpr (NW == 1) {
@@ -606,6 +610,23 @@ __device__ __forceinline__ int pre_next_task(const MpcArgs& a, unsigned long lon
     __syncthreads();
   }
   return task;
+}
+// end of a slice: may this solve be parked (a taker is granted) or does the workgroup go on with it?  Same answer in every thread.
+template <int NW>
+__device__ __forceinline__ bool pre_may_park(const MpcArgs& a, unsigned long long* sh, int tid) {
+  int ok = 0;
+  if (tid == 0) ok = pre_claim(a) ? 1 : 0;
+  if constexpr (NW == 1) {
+    ok = __builtin_amdgcn_readfirstlane(ok);
+  } else {
+    int* si = reinterpret_cast<int*>(sh);
+    __syncthreads();
+    if (tid == 0) si[0] = ok;
+    __syncthreads();
+    ok = si[0];
+    __syncthreads();
+  }
+  return ok != 0;
 }
 // priority level of a solve parked at iteration `iter` (tid 0): r, r_prev = max(primal residual / tolerance, dual residual /
 // tolerance) at this and at the previous adaptive-rho test of this slice (0: none)
@@ -630,8 +651,7 @@ __device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool park
       const unsigned slot = __hip_atomic_fetch_add(&a.pre_ctr[kPreLevelWord + 2 * level + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (slot < (unsigned)a.pre_cap) __hip_atomic_store(&a.pre_queue[(size_t)level * a.pre_cap + slot], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else pre_set_error(a, 2u);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the level's tail is out before the gate opens for one more taker
-      __hip_atomic_fetch_add(&a.pre_ctr[kPreTail], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&a.pre_ctr[kPreParks], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (bookkeeping: solves parked in total)
     } else {
       __hip_atomic_fetch_add(&a.pre_ctr[kPreDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -701,11 +721,11 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     seq_s = task / a.B;
     b = task - seq_s * a.B;
   } else if constexpr (PRE) {
-    if ((int)blockIdx.x < a.B) {
-      b = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    if ((int)blockIdx.x + a.pre_block0 < a.B) {
+      b = a.order ? a.order[blockIdx.x] : blockIdx.x;  // (index-dealt workgroups are always launched with pre_block0 == 0)
     } else {
       b = pre_next_task<NW>(a, &L.sBal[0], tid);
-      if (b < 0) return;  // every instance has finished (or the queue gave up: the error word is set)
+      if (b < 0) return;  // nothing to take (or the error word is set)
     }
   } else {
     b = a.order ? a.order[blockIdx.x] : blockIdx.x;
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   if constexpr (PRE) {
     // (agent-scope atomic loads: what another workgroup of THIS launch stored must never be served from a scalar or stale cache)
     const int pit = __hip_atomic_load(&a.pause_it[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)blockIdx.x >= a.B) it_resume = pit;
+    if ((int)blockIdx.x + a.pre_block0 >= a.B) it_resume = pit;
     else aborted = (pit != 0);
   }
   const bool resumed = PRE && it_resume > 0;
@@ -1121,6 +1141,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const double cs = pCs.get();
 
   PH(8);
+  // (PRE: from here on it_resume is the iteration this workgroup's CURRENT time slice began at -- it moves when a slice ends
+  // without a taker being granted and the solve goes on in place; no second variable: the N = 32 kernels have no scalar to spare)
   for (iter = it_resume + 1; iter <= max_iter; iter++) {
     PH(9);
     if (need_factor) {
@@ -1512,8 +1534,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           tr[0] = pri_res / (eps_abs + eps_rel * last_np); tr[1] = dua_res / (eps_abs + eps_rel * last_nd); tr[2] = rho;
         }
 #endif
-        if constexpr (PRE) {  // end of this workgroup's time slice: park the solve here (after the rho test, before iteration iter + 1)
-          if (iter - it_resume >= a.pre_chunk && iter < max_iter) parked = true;
+        if constexpr (PRE) {  // end of this workgroup's time slice (after the rho test, before iteration iter + 1): park the solve
+          // here if a taker workgroup is granted for it, go on with the next slice in place otherwise (pre_next_task above)
+          if (iter - it_resume >= a.pre_chunk && iter < max_iter) {
+            if (pre_may_park<NW>(a, &L.sBal[0], tid)) parked = true;
+            else it_resume = iter;
+          }
           if (tid == 0) {  // how far from termination (the queue's priority level is predicted from two consecutive tests, at the park)
             double* pr = &L.sPre[(iter / 200 & 1) * 4];
             pr[0] = pri_res; pr[1] = last_np; pr[2] = dua_res; pr[3] = last_nd;
@@ -1720,12 +1746,28 @@ int mpc_order_launch(const int* iters, float* ema, int* order, int B, hipStream_
 }
 
 // preemptive launch (N > 16 only): B * pre_cmax workgroups, the caller has reset pre_queue (-1) and pre_ctr (0) on the stream
-int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream) {
-  if (a.N <= 16 || a.N > kMpcMaxN || !a.pre_queue || !a.pre_ctr || !a.pause_it || a.pre_chunk < 200 || a.pre_cmax < 1 || a.pre_levels < 1 ||
-      a.pre_levels > kPreMaxLevels || a.pre_bin < 1) return -1;
-  const unsigned blocks = (unsigned)a.B * (unsigned)a.pre_cmax;
-  if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false, true>), dim3(blocks), dim3(128), 0, stream, a);
-  else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+int mpc_preemptive_launch(const MpcArgs& a_in, int resident_slots, hipStream_t stream) {
+  if (a_in.N <= 16 || a_in.N > kMpcMaxN || !a_in.pre_queue || !a_in.pre_ctr || !a_in.pause_it || a_in.pre_chunk < 200 || a_in.pre_cmax < 1 ||
+      a_in.pre_levels < 1 || a_in.pre_levels > kPreMaxLevels || a_in.pre_bin < 1) return -1;
+  MpcArgs a = a_in;
+  auto go = [&](unsigned blocks) {
+    if (a.N == 32) hipLaunchKernelGGL((mpc_solve_kernel<2, true, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((mpc_solve_kernel<2, false, false, true>), dim3(blocks), dim3(128), 0, stream, a);
+  };
+  const unsigned takers = (unsigned)a.B * (unsigned)(a.pre_cmax - 1);
+  if (a.B > resident_slots || takers == 0u) {
+    // one grid: the takers (index >= B) start when index-dealt workgroups end, i.e. when first slices have been parked
+    a.pre_block0 = 0;
+    go((unsigned)a.B + takers);
+  } else {
+    // the whole batch is resident at once: takers of the same grid would all start, find nothing parked yet and leave.  Two
+    // grids on the stream instead: every first slice, then the takers (each solve longer than a slice is parked once, resumed
+    // by a taker and -- the other takers having left -- finished in place)
+    a.pre_block0 = 0;
+    go((unsigned)a.B);
+    a.pre_block0 = a.B;
+    go(takers);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -59,6 +59,7 @@ struct qrw_handle_s {
   unsigned* pre_ctr = nullptr;
   int* pause_it = nullptr;
   int pre_chunk = 0, pre_cmax = 0, pre_min_batch = 0, pre_levels = 1, pre_bin = 200;
+  int pre_slots = 0;  // two-wavefront instances resident at a time (2 per compute unit)
   unsigned* pre_err_host = nullptr;  // pinned, host-mapped: the kernel's give-up code of a time-sliced launch (read on entry of the next)
   unsigned* pre_err_dev = nullptr;   // its device address
   bool force_giveup = false;         // tests (QRW_PREEMPT_FORCE_GIVEUP=1): every time-sliced launch starts with its error word set
@@ -258,7 +259,7 @@ static int mpc_known_answer_check(int N, int mode, KatResult* res) {
   if (mode == kKatSliced) {
     a.pre_chunk = kChunk; a.pre_cmax = kCmax; a.pre_cap = kCmax - 1; a.pre_levels = kLevels; a.pre_bin = 200;
     a.pre_queue = (int*)bq.p; a.pre_ctr = (unsigned*)bc.p; a.pause_it = ip + 8;
-    lrc = qrw::mpc_preemptive_launch(a, st.s);
+    lrc = qrw::mpc_preemptive_launch(a, /*resident_slots=*/1 << 20, st.s);  // (one instance: always the two-grid form)
   } else if (mode == kKatSequence) {
     a.seq_K = 1; a.queue = (int*)bq.p; a.qctr = (unsigned*)bc.p; a.seq_hot = ip + 9; a.seq_first = ip + 10; a.seq_groups = 1; a.seq_iters = ip + 11;
     lrc = qrw::mpc_sequence_launch(a, st.s);
@@ -380,6 +381,7 @@ extern "C" int qrw_create(const qrw_config* cfg, qrw_handle* out) {
       h->pre_chunk = chunk;
       h->pre_cmax = (4000 + chunk - 1) / chunk;
       h->pre_min_batch = 2 * prop.multiProcessorCount;  // two two-wavefront instances per compute unit are resident
+      h->pre_slots = h->pre_min_batch;
       if (const char* mb = getenv("QRW_PREEMPT_MIN_BATCH")) h->pre_min_batch = atoi(mb);  // tests: slice small batches too
       ALLOC(h->pause_it, B * sizeof(int));
       ALLOC(h->pre_ctr, qrw::kPreCtrWords * sizeof(unsigned));
@@ -478,7 +480,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
       char msg[256];
       snprintf(msg, sizeof(msg), "qrw_mpc_solve: an earlier time-sliced MPC launch of this handle gave up (code %u: %s); its unfinished "
                "instances hold NaN results and restart cold at the next call", code,
-               code == 2u ? "a priority level's queue overran" : code == 9u ? "forced by QRW_PREEMPT_FORCE_GIVEUP" : "a workgroup waited for a parked solve without any slice ending");
+               code == 2u ? "a priority level's queue overran" : code == 9u ? "forced by QRW_PREEMPT_FORCE_GIVEUP" : "a parked solve reserved for a taker workgroup did not arrive");
       return fail(-12, msg);
     }
   }
@@ -508,7 +510,7 @@ extern "C" int qrw_mpc_solve(qrw_handle h, const double* d_xref, const double* d
              "qrw_mpc_solve: forced give-up");
     }
     debug_poison_lds((hipStream_t)stream);
-    if (qrw::mpc_preemptive_launch(a, (hipStream_t)stream) != 0 ||
+    if (qrw::mpc_preemptive_launch(a, h->pre_slots, (hipStream_t)stream) != 0 ||
         qrw::mpc_pre_error_flush(h->pre_ctr, h->pre_err_dev, (hipStream_t)stream) != 0)
       return fail(-11, "qrw_mpc_solve: kernel launch failed", hipGetLastError());
   } else {
@@ -665,8 +667,8 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
     unsigned c[qrw::kPreCtrWords];
     HIP_OK(d2h(h, c, h->pre_ctr, sizeof(c)), "D2H pre_ctr");
     HIP_OK(host_done(h), "D2H pre_ctr");
-    if (c[qrw::kPreErrWord] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch gave up waiting for a parked solve (2 s without progress) "
-                                     "or overran its queue; results of that call are incomplete");
+    if (c[qrw::kPreErrWord] != 0) return fail(-12, "qrw_mpc_get_stats: the last time-sliced MPC launch left solves unfinished (a parked solve did not reach its taker "
+                                     "within 2 s, or a queue overran); results of that call are incomplete");
   }
   if (h_iters) HIP_OK(d2h(h, h_iters, h->mpc_iters, B * sizeof(int)), "D2H iters");
   if (h_status) HIP_OK(d2h(h, h_status, h->mpc_status, B * sizeof(int)), "D2H status");

@@ -83,16 +83,20 @@ struct MpcArgs {
   int pre_levels;     // 1: one FIFO (plain round robin); > 1: level 0 = solves parked after their first slice, levels 1.. by the
                       // remaining iterations predicted from the residuals' decay (most first), pre_bin iterations per level
   int pre_bin;
+  int pre_block0;     // index of this launch's first workgroup in the B * pre_cmax grid (0; B for the takers' own launch of a
+                      // batch that is resident all at once, mpc_preemptive_launch)
 };
 constexpr int kPreMaxLevels = 9;
-// pre_ctr words (one layout for the kernel, mpc_kernel.hip, and the host readers, qrw_api.hip): tickets drawn by takers, solves
-// parked in total, finished instances, error (1, 3, 4: a taker gave up waiting; 2: a level's queue overran), progress (chunks
-// ended: the give-up clock restarts on it); head of level l at kPreLevelWord + 2 l, its tail at + 2 l + 1
-constexpr int kPreTicketWord = 0, kPreParksWord = 16, kPreDoneWord = 32, kPreErrWord = 33, kPreProgressWord = 34;
+// pre_ctr words (one layout for the kernel, mpc_kernel.hip, and the host readers, qrw_api.hip): takers that took a solve, solves
+// parked in total, finished instances, error (3, 4: a taker's solve, reserved for it, did not arrive; 2: a level's queue overran;
+// 9: forced by a test), progress (chunks ended: the give-up clock restarts on it), claims (taker workgroups spoken for: by a solve
+// parked for them, or by leaving empty-handed); head of level l at kPreLevelWord + 2 l, its tail at + 2 l + 1
+constexpr int kPreTicketWord = 0, kPreParksWord = 16, kPreDoneWord = 32, kPreErrWord = 33, kPreProgressWord = 34, kPreClaimsWord = 40;
 constexpr int kPreLevelWord = 48;
 constexpr int kPreCtrWords = kPreLevelWord + 2 * kPreMaxLevels + 14;
-static_assert(kPreProgressWord < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
-int mpc_preemptive_launch(const MpcArgs& a, hipStream_t stream);
+static_assert(kPreProgressWord < kPreClaimsWord && kPreClaimsWord < kPreLevelWord && kPreLevelWord + 2 * kPreMaxLevels <= kPreCtrWords, "pre_ctr too small");
+// resident_slots: two-wavefront instances the device holds at a time (a batch that fits is launched as two grids, see there)
+int mpc_preemptive_launch(const MpcArgs& a, int resident_slots, hipStream_t stream);
 int mpc_pre_error_flush(const unsigned* pre_ctr, unsigned* host_word, hipStream_t stream);  // error word -> host-mapped word, if set
 
 int mpc_launch(const MpcArgs& a, hipStream_t stream);

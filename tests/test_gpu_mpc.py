@@ -545,10 +545,12 @@ def test_time_sliced_launch_is_independent_of_the_slicing(synth_mod, N, B, chunk
 
 
 def test_time_sliced_launch_bookkeeping(synth_mod, monkeypatch):
-    """The queue's own accounts after a time-sliced launch (qrw_mpc_get_slice_stats): every instance counted as finished,
-    exactly ceil(iterations / slice) - 1 parks per solve over all levels, of which the first parks (one per solve longer than
-    a slice) sit in level 0 and the later ones in the predicted-remainder levels -- more than one of them in use --, and at
-    least as many takers as parks (every parked solve found its taker)."""
+    """The queue's own accounts after a time-sliced launch (qrw_mpc_get_slice_stats): every instance counted as finished; a
+    solve is parked at the end of a slice only when a taker workgroup is granted for it (otherwise it goes on in place: nobody
+    waits), so there are AT MOST ceil(iterations / slice) - 1 parks per solve -- and most of them while the batch outnumbers
+    the resident slots --, at most one first park per solve longer than a slice (level 0), later ones in the
+    predicted-remainder levels -- more than one of them in use --, and EXACTLY as many takers that took a solve as parks
+    (every parked solve found its taker, once)."""
     import torch
 
     import qrw_hip
@@ -567,10 +569,11 @@ def test_time_sliced_launch_bookkeeping(synth_mod, monkeypatch):
         parks = st["parks_per_level"].astype(np.int64)
         assert st["levels"] == 9 and st["chunk"] == chunk and st["finished"] == B
         slices = -(-it // chunk)
-        assert parks.sum() == (slices - 1).sum(), (s, parks, (slices - 1).sum())
-        assert parks[0] == (it > chunk).sum(), (s, parks[0], (it > chunk).sum())
+        print("step %d: parks per level %s of at most %d, takers %d" % (s, parks.tolist(), (slices - 1).sum(), st["takers"]))
+        assert 0.5 * (slices - 1).sum() <= parks.sum() <= (slices - 1).sum(), (s, parks, (slices - 1).sum())
+        assert 0.5 * (it > chunk).sum() <= parks[0] <= (it > chunk).sum(), (s, parks[0], (it > chunk).sum())
         assert (parks[1:] > 0).sum() >= 3, parks
-        assert st["takers"] >= parks.sum()
+        assert st["takers"] == parks.sum()
 
 
 def test_time_sliced_launch_matches_the_oracle(oracle_mod, synth_mod, monkeypatch):
