@@ -25,7 +25,10 @@ def new_vref(scale):
 
 
 with torch.cuda.stream(torch.cuda.Stream(dev)):
-    ctl = Controller_batch(B, q_init, groups=1, multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N, N_gait=max(20, N + 4))
+    # QRW_LOOP_GROUPS=auto: the object Controller_batch builds by itself at this fleet size (two staggered stream groups)
+    grp = os.environ.get("QRW_LOOP_GROUPS", "1")
+    ctl = Controller_batch(B, q_init, groups=(None if grp == "auto" else int(grp)), multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N,
+                           N_gait=max(20, N + 4))
     vref = new_vref(0.5)
     qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0
     qf[:, 7:] = torch.from_numpy(q_init).to(dev)
