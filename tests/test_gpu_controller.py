@@ -324,6 +324,73 @@ def test_control_pre_without_mpc_inputs_leaves_the_rest_unchanged():
         assert np.array_equal(engs[0].planner_get(14, 12 * 20, b), engs[1].planner_get(14, 12 * 20, b)), b
 
 
+def test_bound_iteration_equals_the_two_separate_calls():
+    """qrw_iteration_bind / qrw_iteration_step (an iteration that does not solve on buffers bound once: one foreign call) against
+    qrw_control_pre (without the MPC's inputs) + qrw_wbc_compute_result with every pointer passed per call: every output of both
+    launches bit for bit over 24 iterations, with a per-robot joystick-code tensor, the MPC result alternating between two
+    buffers (the loop adopts results into different ones), and a re-bind half-way (other input tensors)."""
+    import torch
+
+    import qrw_hip
+
+    B, N = 70, 16
+    rng = np.random.default_rng(33)
+    engs = [qrw_hip.Batch(B, N) for _ in range(2)]
+    for e in engs:
+        e.planner_init()
+        e.controller_init(_t(np.tile(Q_INIT, (B, 1))))
+    vref = _t(rng.uniform(-0.4, 0.4, (B, 6)) * np.array([1.5, 0.8, 0, 0, 0, 1.0]))
+    code = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    x_fs = []
+    for _ in range(2):
+        x = np.zeros((B, 24, N))
+        x[:, 2, :], x[:, 14::3, :] = 0.2229, 6.0 + rng.uniform(-0.5, 0.5, (B, 4, 1)).repeat(N, axis=2)
+        x_fs.append(_t(x))
+    qf_np = np.zeros((B, 19))
+    qf_np[:, 2], qf_np[:, 6], qf_np[:, 7:] = 0.2229, 1.0, Q_INIT
+    # the bound side's fixed input tensors (two sets: the second half of the test binds again)
+    sets = [tuple(torch.zeros(shape, dtype=torch.float64, device="cuda") for shape in ((B, 19), (B, 18), (B, 3), (B, 12))) for _ in range(2)]
+    pre = [None, None]
+    post = [None, None]
+    # one ordinary call on each side creates the output buffers (k = 1: does not solve)
+    for i, e in enumerate(engs):
+        qf, vf, rpy, vs = sets[0]
+        qf.copy_(_t(qf_np))
+        pre[i] = e.control_pre(1, vref, qf, vf, rpy, code, x_f_mpc=x_fs[0], mpc_inputs=False)
+        fc = pre[i]["feet_cmd"]
+        post[i] = e.wbc_compute_result(pre[i]["q_wbc"], pre[i]["b_v"], pre[i]["f_cmd"], pre[i]["contacts"], fc[0], fc[1], fc[2], qf, vs)
+    step = None
+    for k in range(2, 26):
+        qf, vf, rpy, vs = sets[0 if k < 14 else 1]
+        qf.copy_(_t(qf_np + np.pad(rng.uniform(-0.02, 0.02, (B, 12)), ((0, 0), (7, 0)))))
+        vf.zero_()
+        vf[:, :6] = vref + _t(rng.uniform(-0.05, 0.05, (B, 6)))
+        rpy.copy_(_t(rng.uniform(-0.02, 0.02, (B, 3))))
+        vs.copy_(_t(rng.uniform(-1, 1, (B, 12))))
+        if k == 12:
+            code[::3] = 2  # some robots are told to change gait
+        x_f = x_fs[k & 1]
+        # side 0: the two calls, every pointer per call
+        pre[0] = engs[0].control_pre(k, vref, qf, vf, rpy, code, x_f_mpc=x_f, out=pre[0], mpc_inputs=False)
+        fc = pre[0]["feet_cmd"]
+        post[0] = engs[0].wbc_compute_result(pre[0]["q_wbc"], pre[0]["b_v"], pre[0]["f_cmd"], pre[0]["contacts"], fc[0], fc[1], fc[2],
+                                             qf, vs, out=post[0])
+        # side 1: bound once per set of input tensors, then one foreign call per iteration
+        if step is None or k == 14:
+            step = engs[1].bind_iteration(pre[1], post[1], (vref, qf, vf, rpy, vs, code))
+        step(k, x_f)
+        torch.cuda.synchronize()
+        for key in ("q", "v", "h_v", "v_ref", "oRh_oTh", "target", "feet_pva", "contacts", "x_f_wbc", "q_wbc", "b_v", "f_cmd", "feet_cmd"):
+            assert torch.equal(pre[0][key], pre[1][key]), (k, key)
+        assert torch.equal(pre[0]["xref"][:, :, :2], pre[1]["xref"][:, :, :2])
+        for key in ("tau_ff", "qdes", "vdes", "f_with_delta", "ddq_res", "feet", "result", "error_flag"):
+            assert torch.equal(post[0][key], post[1][key]), (k, key)
+    with pytest.raises(qrw_hip.QrwError):  # a handle without bound buffers refuses the step
+        fresh = qrw_hip.Batch(B, N)
+        fresh.planner_init()
+        qrw_hip._check(fresh._lib.qrw_iteration_step(fresh._handle, 3, x_fs[0].data_ptr(), None), "qrw_iteration_step")
+
+
 @pytest.mark.parametrize("mode", ["sync", "async_lag2"])
 def test_stream_groups_controller_equals_the_single_handle(mode):
     """Controller_batch(..., groups=2) (Controller_groups: the fleet as two independent stream groups, opt-in) against the
