@@ -101,7 +101,7 @@ int qrw_mpc_get_gait(qrw_handle h, int32_t b, double *h_gait, double *h_Sgait);
  * scripts/LoggerControl.py:61-65,142-143) to recompute `mpc_x_f` (:76,:152), or open-loop evaluation sweeps — not for a
  * closed control loop, whose next inputs depend on this call's result.  A diagnostic for an out-of-scope consumer (log
  * replay), not part of the control path.  d_out is pre-filled with NaN and d_iters with -1, so a call that never ran cannot
- * be mistaken for a result.  qrw_mpc_sequence_error synchronises the device and reports whether any workgroup gave up
+ * be mistaken for a result.  qrw_mpc_sequence_error waits for the handle's sequence launch and reports whether any workgroup gave up
  * waiting for a task (2 s without ANY task of the sequence finishing -- the clock restarts on observed progress, so the
  * length of K or of one instance's chain does not matter; never expected).  Forward progress assumes that workgroups of one
  * launch start in index order (true of the hardware dispatcher; also on CU-masked streams, where fewer are resident). */

@@ -78,7 +78,7 @@ struct MpcArgs {
   int pre_cmax;       // most slices one solve can need = workgroups per instance in the grid
   int pre_cap;        // slots in pre_queue = B * (pre_cmax - 1)
   int* pre_queue;     // [pre_levels][pre_cap] parked instances, one FIFO per priority level, -1 = not filled yet
-  unsigned* pre_ctr;  // [kPreCtrWords] tickets / parks / finished / error / progress / per-level head and tail (mpc_kernel.hip)
+  unsigned* pre_ctr;  // [kPreCtrWords] takers that took a solve / parks / finished / error / progress / claims / per-level head and tail
   int* pause_it;      // [B] iteration a solve was parked at, 0 = not parked
   int pre_levels;     // 1: one FIFO (plain round robin); > 1: level 0 = solves parked after their first slice, levels 1.. by the
                       // remaining iterations predicted from the residuals' decay (most first), pre_bin iterations per level

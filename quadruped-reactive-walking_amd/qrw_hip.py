@@ -624,7 +624,7 @@ class Batch:
 
     def mpc_slice_stats(self):
         """Diagnostic: bookkeeping of the last time-sliced solve (N > 16, batch above the resident slots): priority levels and
-        slice length in use, solves parked into each level, taker workgroups that drew a ticket, finished instances."""
+        slice length in use, solves parked into each level, taker workgroups that took a parked solve, finished instances."""
         lv, ch, tk, fin = C.c_int32(0), C.c_int32(0), C.c_uint32(0), C.c_uint32(0)
         parks = np.zeros(9, np.uint32)
         _check(self._lib.qrw_mpc_get_slice_stats(self._handle, C.cast(C.byref(lv), _vp), C.cast(C.byref(ch), _vp),
