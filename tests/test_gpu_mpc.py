@@ -703,3 +703,33 @@ def test_full_gait_table_without_a_zero_row(oracle_mod, synth_mod, N):
     ga, Sa = a.mpc_gait(0)
     gb, Sb = b.mpc_gait(0)
     assert np.array_equal(ga, gb[:N]) and np.array_equal(Sa, Sb) and np.array_equal(ga, refs[0].get_gait())
+
+
+@pytest.mark.parametrize("scale", [5.0, 12.0])
+def test_large_disturbances_with_saturated_forces(oracle_mod, synth_mod, scale):
+    """States far from the reference (the synthetic state noise times 5 / 12, reference velocities times 1.6: up to 0.6 rad of
+    roll / pitch error, 1.2 m/s of velocity error) on trot / bounding / pacing / walk: vertical forces sit on their 25 N bound
+    (src/MPC.cpp:293-300) and friction-cone rows are active over much of the horizon, solves take up to ~2 000 ADMM iterations
+    with several rho updates.  HIP against the oracle: iteration counts, status, rho, results."""
+    import qrw_hip
+
+    B, N = 48, 16
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "bounding", "pacing", "walk"), seed0=880000)
+    sb.noise_x0 *= scale
+    sb.vref *= 1.6
+    eng = qrw_hip.Batch(B, N)
+    ref = oracle_mod.MPCBatch(B, 0.02, N, 0.32, 20, fast=False)
+    threads = max(1, min(16, len(__import__("os").sched_getaffinity(0))))
+    saturated = 0
+    for s in range(4):
+        d = sb.step(s)
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        st = eng.mpc_stats()
+        r = ref.run(s, d["xref"], d["fsteps"], threads)
+        it, stat = ref.iters()
+        assert np.array_equal(st["iters"], it) and np.array_equal(st["status"], stat), (s, st["iters"][:8], it[:8])
+        for b in range(B):
+            assert max(rel_err(out[b, :12], r[b, :12]), rel_err(out[b, 12:], r[b, 12:])) < RTOL, (s, b)
+        saturated += int((r[:, 14::3, :] > 24.99).sum())
+    assert saturated > 50  # the bound is really active in this test
+    assert st["iters"].max() >= 1000
