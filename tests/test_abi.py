@@ -65,7 +65,6 @@ def test_shipped_sources_hold_no_wrong_result_paths(tmp_path):
 
 
 def test_loader_refuses_a_wrong_results_build(tmp_path, monkeypatch):
-    import importlib
     import shutil
 
     import qrw_hip
