@@ -66,6 +66,60 @@ def test_planner_step_matches_oracle(oracle_mod):
             assert bool(eng.planner_get(3, 1, b)[0]) == fl["new_phase"] and bool(eng.planner_get(4, 1, b)[0]) == fl["is_static"]
 
 
+def test_planner_long_run_with_random_gait_changes(oracle_mod):
+    """1 500 iterations (three seconds of robot time) of the batched planners on the device path with per-robot joystick codes
+    changing at random times (pacing, bounding, trot, static, walk and back), reference velocities re-drawn on the way and the
+    yaw-rate == 0 branches kept in: gait matrices, reference states, footstep table, targets and foot trajectories against the
+    oracle on every iteration (src/Gait.cpp:184-260, src/FootstepPlanner.cpp:51-221, src/FootTrajectoryGenerator.cpp:41-151,
+    src/StatePlanner.cpp:21-61)."""
+    import torch
+
+    import qrw_hip
+
+    B, N = 8, 16
+    rng = np.random.default_rng(2026)
+    eng = qrw_hip.Batch(B, N)
+    eng.planner_init()
+    refs = [oracle_mod.Planner() for _ in range(B)]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    vref = rng.uniform(-0.5, 0.5, (B, 6)) * np.array([2, 1, 0, 0, 0, 1.4])
+    vref[0, 5] = 0.0
+    out = None
+    worst = [0.0, 0.0, 0.0]
+    next_change = rng.integers(30, 200, B)
+    for k in range(1500):
+        if k % 400 == 399:
+            vref = rng.uniform(-0.5, 0.5, (B, 6)) * np.array([2, 1, 0, 0, 0, 1.4])
+            vref[1, 5] = 0.0
+        q7 = _inputs(rng, B, k)
+        hv = vref + rng.uniform(-0.1, 0.1, (B, 6))
+        code = np.zeros(B, np.int32)
+        for b in range(B):
+            if k == next_change[b]:
+                code[b] = rng.integers(1, 6)
+                next_change[b] = k + rng.integers(25, 260)
+        out = eng.planner_step(k, t(q7), t(hv), t(vref), t(code), out=out)
+        torch.cuda.synchronize()
+        o = {kk: v.cpu().numpy() for kk, v in out.items()}
+        for b in range(B):
+            r = refs[b]
+            r.step(k, q7[b], hv[b], vref[b], int(code[b]))
+            f, tg, otg = r.footsteps()
+            pos, vel, acc, t0s, tsw = r.feet()
+            assert np.array_equal(o["gait"][b], r.gaits()[1]), (k, b)
+            assert np.array_equal(o["contacts"][b], r.gaits()[1][0]), (k, b)
+            assert np.allclose(o["xref"][b], r.xref(), rtol=1e-12, atol=1e-13), (k, b)
+            assert np.allclose(o["fsteps"][b], f, rtol=1e-11, atol=1e-13), (k, b)
+            assert np.allclose(o["target"][b], otg, rtol=1e-11, atol=1e-13), (k, b)
+            # (the polynomials' high powers cancel: the absolute error scales with the largest value of the trajectory, hundreds of
+            # m/s^2 in the accelerations right after a gait change shortens a swing)
+            for d, ref, tol in ((0, pos, 1e-7), (1, vel, 1e-7), (2, acc, 1e-6)):  # measured worst: 2.4e-9, 2.7e-9, 3.3e-8
+                err = np.abs(o["feet_pva"][b, d] - ref).max() / max(1.0, np.abs(ref).max())
+                worst[d] = max(worst[d], err)
+                assert err < tol, (k, b, d, err)
+    print("planner long run: worst scaled deviation of foot position / velocity / acceleration: %.1e %.1e %.1e" % tuple(worst))
+
+
 def test_planner_dropin_classes_match_oracle(oracle_mod):
     """The reference-named classes called exactly as scripts/Controller.py:119-137,222-241 calls them."""
     import libquadruped_reactive_walking as lqrw
