@@ -85,6 +85,12 @@ def test_closed_loop_other_timings(oracle_mod):
     _closed_loop(oracle_mod, "sync", True, ALT_CFG, 70)
 
 
+def test_closed_loop_three_gait_periods(oracle_mod):
+    """480 iterations (three gait periods, 48 MPC solves per robot): the footstep table has rolled through every phase three times
+    and every foot has flown three times when the comparison with the chained oracles ends."""
+    _closed_loop(oracle_mod, "sync", True, DEFAULT_CFG, 480, B=4)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "separate"])
 @pytest.mark.parametrize("mode", ["sync", "async_lag0", "async_lag3"])
 def test_closed_loop_matches_chained_oracles(oracle_mod, mode, fused):
