@@ -973,7 +973,8 @@ def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 2048, 409
     fits["four_staggered_groups"] = max(ok) if ok else None
     return {"slot_ms": 2.0, "k_mpc": 10, "rows": rows, "largest_batch_with_worst_iteration_inside_the_slot": fits,
             "what": "1:10 control loop paced at dt_wbc = 2 ms, 40 paced iterations (4 of them solve) after 20 warm-up and 40 free-running "
-                    "ones; latency = compute() call until the iteration's PD targets are ready (incl. the two copies that stand in for "
+                    "ones -- the loop's first two solves (QP set-up, cold start: about twice as many ADMM iterations) are not in the figure, "
+                    "as the reference's first iterations would not be; latency = compute() call until the iteration's PD targets are ready (incl. the two copies that stand in for "
                     "the robots); batches tested: %s" % (list(batches),)}
 
 

@@ -23,36 +23,45 @@ class Result:
 AUTO_GROUPS_MIN_BATCH = 2048  # from this fleet size on, groups=None means two stream groups (below: one handle)
 
 
-def auto_groups(batch, groups=None):
+def auto_groups(batch, groups=None, multiprocessing=False):
     """Number of stream groups a fleet of `batch` robots is stepped as when the caller does not say: robots are independent
     (SURVEY.md 8(e)), a launch of the MPC ends with its longest solve while most of the chip is already idle, and from about
     2048 robots on two groups in flight fill that tail (+10 % control steps/s at batch 4096; in the 1:10 loop, staggered,
-    the worst iteration of the fleet takes 3.2 instead of 5.6 ms).  Below that one handle is the faster form."""
+    the worst iteration of the fleet takes 3.2 instead of 5.6 ms).  Below that one handle is the faster form -- and so it is in
+    the asynchronous mode at any size: the solve is off the tick there anyway, and every group would bring its own pair of
+    compute-unit-masked streams (measured at 4096 robots: 0.32 ms median tick as two asynchronous groups, 0.10 ms as one handle)."""
     if groups is not None:
         return int(groups)
+    if multiprocessing:
+        return 1
     return 2 if (int(batch) >= AUTO_GROUPS_MIN_BATCH and int(batch) % 2 == 0) else 1
 
 
 class Controller_batch:
     def __new__(cls, batch, *args, groups=None, **kwargs):
         # more than one group: the fleet as independent stream groups, see Controller_groups
-        if cls is Controller_batch and auto_groups(batch, groups) > 1:
+        mp = kwargs.get("multiprocessing", args[9] if len(args) > 9 else False)  # (position of `multiprocessing` in __init__)
+        if cls is Controller_batch and auto_groups(batch, groups, mp) > 1:
             return super().__new__(Controller_groups)
         return super().__new__(cls)
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
-                 stagger=False, _out_views=None):
+                 stagger=None, _out_views=None):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
 
-        groups: None / 1 = one handle; G > 1 = the fleet as G stream groups (Controller_groups).  Not the default: in the 1:10
-        loop at batch 4096 two groups joined on the caller's stream every iteration run at 9.6 M iterations/s against 10.7 M
-        for the single handle (twice the launches, one join per iteration), never joined (compute_group on the groups' own
-        streams) at 10.95 M; the paced worst-case latency (5.6 ms, the iteration that carries the solve) is the same in all
-        three -- only the asynchronous mode (0.35 ms) removes it (bench.py, secondary_ratio_1_10*).
+        groups: None = chosen from the fleet size (auto_groups: one handle below 2048 robots, two staggered stream groups from
+        there; always one handle in the asynchronous mode); 1 = one handle; G > 1 = the fleet as G stream groups
+        (Controller_groups).  Every robot's results are the single handle's, bit for bit.  Measured at batch 4096 in the 1:10 loop:
+        two groups joined on the caller's stream every iteration and NOT staggered run at 10.0 M iterations/s against 12.4 M for
+        the single handle (twice the launches) with the same worst iteration (5.6 ms, the one that carries the solve) -- which is
+        why automatically chosen groups are staggered: the worst iteration of the fleet drops to 3.1 ms, and 2048 robots fit the
+        reference's 2 ms slot where one handle fits 1024 (bench.py, realtime_slot).
 
-        stagger (groups > 1 only): group g starts g * k_mpc / groups fleet ticks late, so the groups' MPC solves fall on
-        different ticks and one group's solve runs beside the other's plain iterations (Controller_groups).
+        stagger (groups > 1 only; None = True when the groups were chosen automatically, False when `groups` was given):
+        group g starts g * k_mpc / groups fleet ticks late, so the groups' MPC solves fall on different ticks and one
+        group's solve runs beside the other's plain iterations (Controller_groups).  Until a group has started its robots are
+        commanded to hold q_init (Result: P 3, D 0.2, q_des = q_init, zero v_des and tau_ff).
 
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
         on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
@@ -317,7 +326,7 @@ class Controller_groups(Controller_batch):
                  stagger=None, _out_views=None):
         import torch
 
-        G = auto_groups(batch, groups)
+        G = auto_groups(batch, groups, multiprocessing)
         if stagger is None:
             stagger = groups is None  # groups chosen from the fleet size come staggered (see Controller_batch.__init__)
         if G < 2 or int(batch) % G:
@@ -361,6 +370,11 @@ class Controller_groups(Controller_batch):
                     self.Bs, qi[sl], dt_wbc=dt_wbc, dt_mpc=dt_mpc, k_mpc=k_mpc, T_gait=T_gait, T_mpc=T_mpc, N_gait=N_gait,
                     h_ref=h_ref, device=device, multiprocessing=multiprocessing, loop_cus=loop_cus, mpc_lag=mpc_lag, fused=fused,
                     groups=1, _out_views=dict(result=self._fleet_result[sl], error_flag=self.error_flag[sl])))
+
+    @property
+    def loop_stream(self):
+        """None: every group brings its own streams (Controller_batch.loop_stream is a single handle's)."""
+        return None
 
     def slice_of(self, g):
         return self._sl[g]

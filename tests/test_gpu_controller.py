@@ -487,6 +487,9 @@ def test_staggered_stream_groups_equal_single_handles_started_late(free, default
         assert not isinstance(Controller_batch(2046, Q_INIT), Controller_groups)        # below the threshold: one handle
         assert not isinstance(Controller_batch(B, Q_INIT, groups=1), Controller_groups)  # groups=1 stays available
         assert not Controller_batch(B, Q_INIT, groups=2).stagger                         # explicit groups: not staggered unless asked
+        mp = Controller_batch(B, Q_INIT, multiprocessing=True)                          # the asynchronous mode: always one handle
+        assert not isinstance(mp, Controller_groups)
+        mp.stop_parallel_loop()
     else:
         ctl = Controller_batch(B, qi, groups=2, stagger=True, k_mpc=k_mpc)
     assert isinstance(ctl, Controller_groups) and ctl.G == 2 and ctl.stagger and ctl._delay == [0, k_mpc // 2]
