@@ -275,3 +275,54 @@ def test_getters_and_host_calls_wait_for_their_own_handle_only(synth_mod):
     third.close()
     side.close()
     assert (big.mpc_stats()["iters"] == bst["iters"]).all()  # the stream is gone: the getter has nothing to wait for and says the same
+
+
+def test_two_caller_threads_with_their_own_handles(synth_mod):
+    """Handles are single-caller, the library is not: two Python threads (ctypes releases the GIL during the calls), each creating its own
+    handles (the known-answer gate and the registry of live handles are behind mutexes, the error text is thread-local) and stepping
+    MPC + WBC on its own stream, get bit for bit what one thread gets alone."""
+    import threading
+
+    import torch
+    import qrw_hip
+
+    B, N, S = 96, 16, 5
+    sbs = [synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=616000 + 1000 * i) for i in range(2)]
+    data = [[sb.step(s) for s in range(S)] for sb in sbs]
+
+    def run(i, out):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            res = []
+            for rep in range(3):  # handles created and destroyed while the other thread is mid-launch
+                eng = qrw_hip.Batch(B, N)
+                for s in range(S):
+                    d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in data[i][s].items() if k != "gait" and k != "x0"}
+                    o = eng.mpc_solve(d["xref"], d["fsteps"], s)
+                    w = eng.wbc_compute(d["q"], d["dq"], o[:, 12:, 0].contiguous(), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+                torch.cuda.current_stream().synchronize()
+                res.append((o.cpu().numpy().copy(), w["tau_ff"].cpu().numpy().copy(), eng.mpc_stats()["iters"].copy()))
+                eng.close()
+            out[i] = res
+
+    alone = [None, None]
+    for i in range(2):
+        run(i, alone)
+    both = [None, None]
+    errs = []
+
+    def guarded(i):
+        try:
+            run(i, both)
+        except Exception as e:  # pragma: no cover - reported below
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for rep in range(3):
+            for a, b in zip(alone[i][rep], both[i][rep]):
+                assert np.array_equal(a, b), (i, rep)
