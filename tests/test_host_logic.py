@@ -140,3 +140,17 @@ def test_priority_levels_of_the_time_sliced_launch_beat_one_fifo_on_the_recorded
     pol = {k: float(np.mean([x[0] for x in v])) for k, v in sim.policies(its, R).items()}
     assert pol["9 levels of 200, slices of 600 (shipped)"] < 1.05 < 1.08 < pol["one FIFO, slices of 600 (round robin)"] < 1.12
     assert pol["plain launch (no slicing)"] > 1.2 and pol["9 levels of 400, TRUE remaining count"] > 1.02
+
+
+def test_default_groups_of_the_fleet_objects():
+    """Host logic of the default objects (no GPU): one handle below 2048 robots, two stream groups from there, one handle for odd
+    fleets and in the asynchronous mode; Controller_batch.__new__ reads `multiprocessing` from the position it has in __init__."""
+    import inspect
+
+    from Controller import AUTO_GROUPS_MIN_BATCH, Controller_batch, auto_groups
+
+    assert AUTO_GROUPS_MIN_BATCH == 2048
+    assert [auto_groups(b) for b in (1, 64, 2046, 2047, 2048, 2049, 4096, 32768)] == [1, 1, 1, 1, 2, 1, 2, 2]
+    assert auto_groups(4096, multiprocessing=True) == 1 and auto_groups(4096, 4, True) == 4 and auto_groups(64, 2) == 2
+    names = list(inspect.signature(Controller_batch.__init__).parameters)
+    assert names[:2] == ["self", "batch"] and names.index("multiprocessing") - 2 == 9  # args[9] in __new__
