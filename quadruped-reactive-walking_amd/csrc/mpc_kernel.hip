@@ -824,18 +824,30 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   }
   const bool mynz = act && (f3[0] != 0.0 || f3[1] != 0.0 || f3[2] != 0.0);
   const unsigned long long bal = __ballot(mynz);
-  int len = N;
+  // update_ML / construct_S (:422, :669) walk the GAIT matrix to its first all-zero row, and a gait entry is 0 where the
+  // foothold's x is 0 (:691): a row of fsteps whose four x entries are 0 but which is not all zero (only y / z set) does
+  // not end construct_gait, yet it ends the rewriting of B blocks and S flags -- `stop` <= `len`.
+  const unsigned long long balx = __ballot(act && f3[0] != 0.0);
+  int len = N, stop = N;
   if constexpr (NW == 1) {
-    for (int kk = N - 1; kk >= 0; kk--)
+    for (int kk = N - 1; kk >= 0; kk--) {
       if (((bal >> (4 * kk)) & 0xFull) == 0) len = kk;
+      if (((balx >> (4 * kk)) & 0xFull) == 0) stop = kk;
+    }
   } else {
     if (lane == 0) L.sBal[wv] = bal;
     __syncthreads();
     for (int kk = N - 1; kk >= 0; kk--)
       if (((L.sBal[kk >> 4] >> (4 * (kk & 15))) & 0xFull) == 0) len = kk;
     __syncthreads();
+    if (lane == 0) L.sBal[wv] = balx;
+    __syncthreads();
+    for (int kk = N - 1; kk >= 0; kk--)
+      if (((L.sBal[kk >> 4] >> (4 * (kk & 15))) & 0xFull) == 0) stop = kk;
+    __syncthreads();
   }
-  const bool in_gait = k < len;
+  const bool in_table = k < len;   // rows construct_gait rewrites
+  const bool in_gait = k < stop;   // rows update_ML / construct_S rewrite
 
   double Bang[3][3];  // B[9+r][3j+t] of step k (MPC.cpp:440)
   double sfl[3];      // S_gait entries of (k, foot j) (MPC.cpp:665-681)
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     if (first)
       for (int e = tid; e < a.N_gait * 4; e += T) gg[e] = 0;
     __syncthreads();
-    if (act && in_gait) gg[k * 4 + j] = (f3[0] == 0.0) ? 0 : 1;
+    if (act && in_table) gg[k * 4 + j] = (f3[0] == 0.0) ? 0 : 1;
     if (act && k == len && len < a.N_gait) gg[k * 4 + j] = 0;
     if (len == N && N < a.N_gait && tid < 4) gg[N * 4 + tid] = 0;
   }

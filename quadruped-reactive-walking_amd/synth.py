@@ -256,3 +256,119 @@ class SyntheticBatch:
         agoals = np.where(swing, 1.0 * ng[:, 2].transpose(0, 2, 1), 0.0)
         return dict(xref=xref, fsteps=fsteps, gait=gait, q=q, dq=dq, contacts=contacts, pgoals=pgoals,
                     vgoals=vgoals, agoals=agoals, x0=x0)
+
+
+STANCE_SETS = np.array([[(m >> i) & 1 for i in range(4)] for m in range(1, 16)], dtype=np.float64)  # the 15 non-empty ones
+
+
+class RandomContactTables:
+    """Seeded MPC inputs with ARBITRARY contact tables, for parity tests and soaks.
+
+    MPC::construct_gait / update_ML accept any 0/1 table the footstep matrix encodes (src/MPC.cpp:418-464,686-701), not
+    only the five periodic gaits of src/Gait.cpp that SyntheticBatch produces.  Per instance (seed = seed0 + b) and call:
+      - table length anywhere in 1..n_steps (about a third of the tables full length; N_gait == n_steps gives the table
+        without a terminating zero row), the rows after it all zero;
+      - rows drawn in runs of 1..6 from the 15 non-empty stance sets in arbitrary order (single-stance rows included);
+      - footholds up to +-`reach` m from the shoulders in x and y (held over a foot's stance run, re-drawn in a fifth
+        of the rows), z = 0 mostly, a few centimetres otherwise; a stance foot's x is never exactly 0 (it would read
+        as swing, src/MPC.cpp:691);
+      - current state with roll / pitch up to +-0.3 rad, yaw over +-pi, velocities up to +-1.5 m/s and +-1.5 rad/s; the
+        reference trajectory turns and advances at a random constant rate from there (src/StatePlanner.cpp:35-60 shape);
+      - between two calls the table either recedes by one row (a new row appended, as the planner does) or, with
+        probability `p_change`, is drawn afresh: every B block and S flag changes under a warm-started solver.
+    step(c) -> dict(xref (B,12,N+1), fsteps (B,N_gait,12), gait (B,N_gait,4)); deterministic in (seed0, b, c) only if
+    calls are made in order c = 0, 1, 2, ... (the receding tables carry state)."""
+
+    def __init__(self, B, n_steps=16, N_gait=None, dt=0.02, seed0=20600000, reach=0.3, p_change=0.4, b0=0):
+        self.B, self.N, self.dt = B, n_steps, dt
+        self.N_gait = N_gait or max(20, n_steps + 4)
+        assert self.N_gait >= n_steps
+        self.reach, self.p_change = reach, p_change
+        self.rng = [np.random.default_rng(seed0 + b0 + b) for b in range(B)]
+        self.rows = [None] * B   # (L,4) stance sets of the current table
+        self.feet = [None] * B   # (L,4,3) footholds
+        self.next_call = 0
+
+    def _draw_row_run(self, r, n, prev_row=None, prev_feet=None):
+        """n more rows: runs of equal stance sets; a foot keeps its foothold while it stays in stance."""
+        rows, feet = [], []
+        row, ft = prev_row, prev_feet
+        left = 0
+        for _ in range(n):
+            if left == 0 or row is None:
+                new = STANCE_SETS[r.integers(0, 15)]
+                left = int(r.integers(1, 7))
+                nf = np.zeros((4, 3)) if ft is None else ft.copy()
+                for j in range(4):
+                    if new[j] > 0 and (row is None or row[j] == 0):
+                        nf[j] = self._foothold(r, j)
+                row, ft = new, nf
+            elif r.random() < 0.2:
+                ft = ft.copy()
+                j = int(r.integers(0, 4))
+                if row[j] > 0:
+                    ft[j] = self._foothold(r, j)
+            left -= 1
+            rows.append(row)
+            feet.append(ft)
+        return rows, feet
+
+    def _foothold(self, r, j):
+        p = np.array([SHOULDERS[0, j] + r.uniform(-self.reach, self.reach), SHOULDERS[1, j] + r.uniform(-self.reach, self.reach),
+                      0.0 if r.random() < 0.7 else r.uniform(-0.03, 0.03)])
+        if p[0] == 0.0:
+            p[0] = 1e-9
+        return p
+
+    def _fresh_table(self, r):
+        N = self.N
+        L = N if (self.N_gait == N or r.random() < 0.35) else int(r.integers(1, N + 1))
+        rows, feet = self._draw_row_run(r, L)
+        return rows, feet
+
+    def step(self, c):
+        assert c == self.next_call, "RandomContactTables.step must be called with c = 0, 1, 2, ..."
+        self.next_call += 1
+        B, N, dt = self.B, self.N, self.dt
+        xref = np.zeros((B, 12, N + 1))
+        fsteps = np.zeros((B, self.N_gait, 12))
+        gait = np.zeros((B, self.N_gait, 4))
+        t = dt * np.arange(1, N + 1)
+        for b in range(B):
+            r = self.rng[b]
+            if self.rows[b] is None or r.random() < self.p_change:
+                self.rows[b], self.feet[b] = self._fresh_table(r)
+            else:  # recede by one row; the table keeps its length (or grows / shrinks by one now and then)
+                rows, feet = self.rows[b][1:], self.feet[b][1:]
+                want = len(self.rows[b]) + int(r.integers(-1, 2))
+                want = N if self.N_gait == N else min(max(want, 1), N)
+                if len(rows) < want:
+                    more_r, more_f = self._draw_row_run(r, want - len(rows), rows[-1] if rows else None,
+                                                        feet[-1] if feet else None)
+                    rows, feet = rows + more_r, feet + more_f
+                self.rows[b], self.feet[b] = rows[:want], feet[:want]
+            L = len(self.rows[b])
+            R = np.array(self.rows[b])
+            F = np.array(self.feet[b])
+            gait[b, :L] = R
+            fsteps[b, :L] = (F * R[:, :, None]).reshape(L, 12)
+            # current state and reference trajectory
+            x0 = np.zeros(12)
+            x0[0:2] = r.uniform(-0.05, 0.05, 2)
+            x0[2] = H_REF + r.uniform(-0.04, 0.04)
+            x0[3:5] = r.uniform(-0.3, 0.3, 2)
+            x0[5] = r.uniform(-np.pi, np.pi)
+            x0[6:9] = r.uniform(-1.5, 1.5, 3) * np.array([1.0, 1.0, 0.3])
+            x0[9:12] = r.uniform(-1.5, 1.5, 3)
+            v = r.uniform(-1.0, 1.5, 2) * np.array([1.0, 0.4])
+            wz = r.uniform(-1.0, 1.0) if r.random() < 0.8 else 0.0
+            yaw = x0[5] + wz * t
+            xref[b, :, 0] = x0
+            xref[b, 5, 1:] = yaw
+            xref[b, 6, 1:] = v[0] * np.cos(yaw) - v[1] * np.sin(yaw)
+            xref[b, 7, 1:] = v[0] * np.sin(yaw) + v[1] * np.cos(yaw)
+            xref[b, 0, 1:] = x0[0] + np.cumsum(xref[b, 6, 1:]) * dt
+            xref[b, 1, 1:] = x0[1] + np.cumsum(xref[b, 7, 1:]) * dt
+            xref[b, 2, 1:] = H_REF
+            xref[b, 11, 1:] = wz
+        return dict(xref=xref, fsteps=fsteps, gait=gait)

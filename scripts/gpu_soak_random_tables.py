@@ -1,0 +1,51 @@
+"""Soak of the MPC kernels against the CPU oracle on ARBITRARY contact tables (synth.RandomContactTables; the suite's form is
+tests/test_gpu_mpc_random_tables.py).  Per (N, B, K[, full]) block: K warm-started calls of B instances; every solve must take
+the oracle's iteration count and status and match its result to 1e-4.  A mismatch is printed with the (seed0, instance, call)
+that reproduces it.  usage: gpu_soak_random_tables.py [N:B:K[:full] ...]   (default: >= 50 000 solves in total)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import oracle, qrw_hip, synth
+oracle.build(fast=False)
+blocks = sys.argv[1:] or ["16:4096:5", "12:2048:5", "5:2048:4", "16:1024:5:full", "24:1024:5", "32:1024:5", "32:256:5:full"]
+threads = max(1, min(16, len(os.sched_getaffinity(0))))
+total = bad_it = bad_st = bad_res = 0
+worst_all = 0.0
+t_start = time.time()
+for spec in blocks:
+    p = spec.split(":")
+    N, B, K = int(p[0]), int(p[1]), int(p[2])
+    full = len(p) > 3
+    NG = N if full else max(20, N + 4)
+    seed0 = 30000000 + 100000 * N + (50000 if full else 0)
+    gen = synth.RandomContactTables(B, N, N_gait=NG, seed0=seed0)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=NG, T_gait=0.02 * N)
+    ref = oracle.MPCBatch(B, 0.02, N, 0.02 * N, NG, fast=False)
+    worst, its_max, statuses, single = 0.0, 0, set(), 0
+    for c in range(K):
+        d = gen.step(c)
+        single += int((d["gait"].sum(2) == 1).sum())
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], c)
+        st = eng.mpc_stats()
+        r = ref.run(c, d["xref"], d["fsteps"], threads)
+        it, stat = ref.iters()
+        sx = np.maximum(np.abs(r[:, :12]).reshape(B, -1).max(1), 1e-12)
+        sf = np.maximum(np.abs(r[:, 12:]).reshape(B, -1).max(1), 1e-12)
+        e = np.maximum(np.abs(out[:, :12] - r[:, :12]).reshape(B, -1).max(1) / sx, np.abs(out[:, 12:] - r[:, 12:]).reshape(B, -1).max(1) / sf)
+        e = np.where(np.isnan(e), np.inf, e)
+        for name, m in (("iterations", it != st["iters"]), ("status", stat != st["status"]), ("result", e >= 1e-4)):
+            for b in np.nonzero(m)[0][:5]:
+                print("MISMATCH %s: N=%d N_gait=%d seed0=%d instance %d call %d: hip iters %d status %d, oracle iters %d status %d, rel err %.3e"
+                      % (name, N, NG, seed0, b, c, st["iters"][b], st["status"][b], it[b], stat[b], e[b]), flush=True)
+        bad_it += int((it != st["iters"]).sum()); bad_st += int((stat != st["status"]).sum()); bad_res += int((e >= 1e-4).sum())
+        worst = max(worst, float(e.max())); its_max = max(its_max, int(it.max())); statuses |= set(stat.tolist())
+        total += B
+        print("N=%d%s call %d: %d solves, worst rel err %.2e, iterations %d..%d (mean %.0f), statuses %s; so far %d solves, mismatches it/status/result %d/%d/%d, %.0f s"
+              % (N, " full" if full else "", c, B, e.max(), it.min(), it.max(), it.mean(), sorted(set(stat.tolist())), total, bad_it, bad_st, bad_res, time.time() - t_start), flush=True)
+    worst_all = max(worst_all, worst)
+    print("BLOCK N=%d N_gait=%d B=%d K=%d seed0=%d: worst rel err %.3e, max iterations %d, statuses %s, single-stance rows %d"
+          % (N, NG, B, K, seed0, worst, its_max, sorted(statuses), single), flush=True)
+print("SOAK random contact tables: %d solves, worst rel err %.3e, mismatches: iterations %d, status %d, result (>= 1e-4) %d"
+      % (total, worst_all, bad_it, bad_st, bad_res))
+sys.exit(1 if (bad_it or bad_st or bad_res) else 0)

@@ -1,0 +1,212 @@
+"""MPC parity on ARBITRARY contact tables: HIP (through the C ABI) against the CPU oracle.
+
+MPC::construct_gait / update_ML take any 0/1 table the footstep matrix encodes (/root/reference/src/MPC.cpp:418-464,
+665-701), not only the five periodic gaits of src/Gait.cpp the other parity tests draw from.  synth.RandomContactTables:
+every row one of the 15 non-empty stance sets (single-stance rows included) in arbitrary order and run lengths, table
+length anywhere in 1..n_steps (and the full table without a zero row, N_gait == n_steps), footholds up to +-0.3 m from the
+shoulders, yaw over +-pi, large state errors, and tables that change completely between two warm-started calls.  The
+assertions are run_sequence's (iteration count, status, rho -- to 1e-5 here, see check_against_oracle --, result to 1e-4; measured <= 2e-6) on every instance
+and call, and the launch forms (plain, sequence, time-sliced) must agree with each other the way their own tests demand.
+The soak of the same generator (>= 50 000 solves) is scripts/gpu_soak_random_tables.py -> profiles/r6_soak_parity_random_tables.txt."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(a, ref):
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)
+
+
+def _threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def check_against_oracle(eng, ref, d, c, out):
+    """run_sequence's assertions (tests/test_gpu_mpc.py:15-40), every instance of one call."""
+    r = ref.run(c, d["xref"], d["fsteps"], _threads())
+    it, st = ref.iters()
+    g = eng.mpc_stats()
+    assert np.array_equal(g["iters"], it), (c, np.nonzero(g["iters"] != it)[0][:8], g["iters"][g["iters"] != it][:8], it[g["iters"] != it][:8])
+    assert np.array_equal(g["status"], st), c
+    rho = np.array([ref._lib.mpc_oracle_rho(h) for h in ref._hs])
+    # rho: 1e-9 in run_sequence on the periodic gaits.  On these inputs the adapted rho (rho * sqrt of a ratio of residual
+    # norms that are differences of O(10) terms, taken every 200 iterations) moves by up to 1.7e-7 relative between two
+    # builds of the SAME oracle source (strict IEEE against -O3 -march=native with FMA contraction: measured on the
+    # N = 12 / 24 cases below), and by up to 8e-7 between kernel and oracle -- rounding, not logic: iteration counts and
+    # statuses stay identical and results agree to ~1e-7.  Hence 1e-5 here.
+    assert np.allclose(g["rho"], rho, rtol=1e-5, atol=0), (c, np.abs(g["rho"] / rho - 1).max())
+    assert np.array_equal(np.isnan(out), np.isnan(r)), c
+    worst = 0.0
+    for b in range(out.shape[0]):
+        e = max(rel_err(out[b, :12], r[b, :12]), rel_err(out[b, 12:], r[b, 12:]))
+        assert e < RTOL, (c, b, e)
+        worst = max(worst, e)
+    return worst, it
+
+
+@pytest.mark.parametrize("N,B,full", [(5, 40, False), (12, 40, False), (16, 48, False), (24, 36, False), (32, 36, False),
+                                      (16, 16, True), (32, 12, True), (1, 8, False), (17, 8, False)])
+def test_random_contact_tables_match_oracle_in_every_launch_form(oracle_mod, synth_mod, N, B, full, monkeypatch):
+    import torch
+
+    import qrw_hip
+
+    K = 5
+    N_gait = N if full else max(20, N + 4)
+    gen = synth_mod.RandomContactTables(B, N, N_gait=N_gait, seed0=20600000 + 1000 * N + (500 if full else 0))
+    steps = [gen.step(c) for c in range(K)]
+    lens = np.array([(s["gait"].sum(2) > 0).sum(1) for s in steps])
+    singles = sum(int(((s["gait"].sum(2) == 1)).sum()) for s in steps)
+    assert singles > 0 and (full or N == 1 or lens.min() < lens.max())  # the generator does what the docstring says
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", "0")
+    plain = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    seq = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    ref = oracle_mod.MPCBatch(B, 0.02, N, 0.02 * N, N_gait, fast=False)  # the strict checker build
+    dev = torch.device("cuda", 0)
+    xs = torch.from_numpy(np.stack([s["xref"] for s in steps])).to(dev)
+    fs = torch.from_numpy(np.stack([s["fsteps"] for s in steps])).to(dev)
+    outs, its, stats = [], [], []
+    worst, seen = 0.0, set()
+    for c in range(K):
+        out = plain.mpc_solve(xs[c], fs[c], c).cpu().numpy()
+        w, it = check_against_oracle(plain, ref, steps[c], c, out)
+        worst = max(worst, w)
+        g = plain.mpc_stats()
+        seen |= set(g["status"].tolist())
+        outs.append(out)
+        its.append(it.copy())
+        stats.append({k: g[k].copy() for k in ("iters", "status", "rho")})
+        gait, _ = plain.mpc_gait(B - 1)
+        L = lens[c][B - 1]
+        assert np.array_equal(gait[:L], steps[c]["gait"][B - 1, :L].astype(gait.dtype)), c
+    # the sequence launch: the K calls of every instance in one launch, bit for bit what K launches give
+    sit = torch.zeros((K, B), dtype=torch.int32, device=dev)
+    so = seq.mpc_solve_sequence(xs, fs, 0, iters=sit)
+    torch.cuda.synchronize()
+    assert not seq.mpc_sequence_timed_out()
+    assert np.array_equal(sit.cpu().numpy(), np.stack(its))
+    assert np.array_equal(so.cpu().numpy(), np.stack(outs), equal_nan=True)
+    if N > 16:
+        # the time-sliced launch: slices of 200 iterations against slices of 3800 bit for bit (same instantiation); against the
+        # plain launch (another instantiation) iteration counts / status exactly and results to rounding
+        monkeypatch.setenv("QRW_PREEMPT_MIN_BATCH", "1")
+        monkeypatch.setenv("QRW_PREEMPT_CHUNK", "3800")
+        whole = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+        monkeypatch.setenv("QRW_PREEMPT_CHUNK", "200")
+        sliced = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+        for c in range(K):
+            w = whole.mpc_solve(xs[c], fs[c], c).cpu().numpy()
+            s = sliced.mpc_solve(xs[c], fs[c], c).cpu().numpy()
+            gw, gs = whole.mpc_stats(), sliced.mpc_stats()
+            for key in ("iters", "status", "rho"):
+                assert np.array_equal(gw[key], gs[key]), (c, key)
+            assert np.array_equal(w, s, equal_nan=True), c
+            assert np.array_equal(gs["iters"], stats[c]["iters"]) and np.array_equal(gs["status"], stats[c]["status"]), c
+            assert np.allclose(gs["rho"], stats[c]["rho"], rtol=1e-5) and rel_err(s, outs[c]) < 1e-6, (c, rel_err(s, outs[c]))
+    print("random tables N=%d B=%d%s: worst relative deviation %.2e, iterations %d..%d, statuses %s, table lengths %d..%d, "
+          "%d single-stance rows" % (N, B, " full" if full else "", worst, min(i.min() for i in its), max(i.max() for i in its),
+                                     sorted(seen), lens.min(), lens.max(), singles))
+
+
+def test_time_sliced_single_grid_form_on_random_tables(synth_mod, monkeypatch):
+    """qrw_create's known answer and the QRW_PREEMPT_MIN_BATCH tests of small batches launch the time-sliced
+    kernel as TWO grids (first slices, then takers); production takes ONE grid once the batch exceeds the resident slots
+    (mpc_preemptive_launch).  A batch just above two instances per compute unit with the default settings -- what a caller
+    gets --: the single-grid launch against the unsliced launch on random tables (iteration counts / status exactly,
+    results to rounding), and its queue accounts closed (every instance finished, every parked solve taken once)."""
+    import torch
+
+    import qrw_hip
+
+    N, N_gait = 32, 36
+    B = 2 * qrw_hip.device_cu_count(0) + 8
+    gen = synth_mod.RandomContactTables(B, N, N_gait=N_gait, seed0=20650000)
+    monkeypatch.setenv("QRW_PREEMPT_CHUNK", "0")
+    plain = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    monkeypatch.delenv("QRW_PREEMPT_CHUNK")
+    monkeypatch.delenv("QRW_PREEMPT_MIN_BATCH", raising=False)
+    sliced = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)  # the defaults
+    dev = torch.device("cuda", 0)
+    parks = 0
+    for c in range(3):
+        d = gen.step(c)
+        x, f = torch.from_numpy(d["xref"]).to(dev), torch.from_numpy(d["fsteps"]).to(dev)
+        a = plain.mpc_solve(x, f, c).cpu().numpy()
+        b = sliced.mpc_solve(x, f, c).cpu().numpy()
+        sa, sb = plain.mpc_stats(), sliced.mpc_stats()
+        assert np.array_equal(sa["iters"], sb["iters"]) and np.array_equal(sa["status"], sb["status"]), c
+        assert np.allclose(sa["rho"], sb["rho"], rtol=1e-5) and rel_err(b, a) < 1e-6, (c, rel_err(b, a))
+        st = sliced.mpc_slice_stats()
+        assert st["finished"] == B and st["takers"] == st["parks_per_level"].sum(), (c, st)
+        parks += int(st["parks_per_level"].sum())
+    assert parks > 0, "no solve was ever parked: the single-grid form's takers were not exercised"
+
+
+def _hand_tables(N, N_gait):
+    """fsteps tables around the corners of construct_gait / update_ML, one per instance (rows beyond those written: zero)."""
+    sh = np.array([0.1946, 0.14695, 0.0, 0.1946, -0.14695, 0.0, -0.1946, 0.14695, 0.0, -0.1946, -0.14695, 0.0])
+    full = np.tile(sh, (N, 1))
+    trot = full.copy()
+    trot[::2, 3:9] = 0.0
+    trot[1::2, 0:3] = 0.0
+    trot[1::2, 9:12] = 0.0
+    tabs = []
+    # 0: a row whose four x entries are 0 while y is set (MPC.cpp:691 reads every foot as swing): the gait row is all zero,
+    #    update_ML / construct_S stop THERE (:422, :669), construct_gait does not (:688) -- later rows keep stale B / S
+    t = trot.copy(); t[N // 2, 0::3] = 0.0; tabs.append(t)
+    # 1: the same at row 0: nothing is rewritten at all
+    t = full.copy(); t[0, 0::3] = 0.0; tabs.append(t)
+    # 2: single-stance rows only, a different foot every row
+    t = np.zeros((N, 12))
+    for k in range(N):
+        j = (k * 3) % 4
+        t[k, 3 * j:3 * j + 3] = sh[3 * j:3 * j + 3]
+    tabs.append(t)
+    # 3: one stance foot whose x is exactly 0 but y is not: reads as swing, the row goes on
+    t = full.copy(); t[2, 0] = 0.0; t[5, 9] = 0.0; tabs.append(t)
+    # 4: z entries only in one row (x = y = 0 for all feet): not an all-zero row, but an all-zero gait row
+    t = trot.copy(); t[3] = 0.0; t[3, 2::3] = 0.01; tabs.append(t)
+    # 5: footholds far from the shoulders, three-stance rows in shuffled order
+    t = full.copy()
+    for k in range(N):
+        t[k, 3 * ((k * 7 + 1) % 4):3 * ((k * 7 + 1) % 4) + 3] = 0.0
+        t[k, 0::3] += 0.3 * (-1) ** k
+        t[k, 1::3] *= np.where(t[k, 1::3] != 0, 1.0 + 0.9 * ((k % 3) - 1), 1.0)
+    t[:, 0::3] = np.where((t[:, 0::3] == 0) & (np.abs(t[:, 1::3]) > 0), 1e-9, t[:, 0::3])
+    tabs.append(t)
+    out = np.zeros((len(tabs), N_gait, 12))
+    for b, t in enumerate(tabs):
+        out[b, :N] = t
+    return out
+
+
+@pytest.mark.parametrize("N", [16, 12, 32, 24])
+def test_gait_rows_that_read_as_all_swing_stop_the_update(oracle_mod, synth_mod, N):
+    """The corners of the footstep-matrix -> gait decoding, by hand (see _hand_tables): calls alternate between these tables
+    and ordinary ones so that 'stale' B blocks and S flags differ from what a rewrite would give.  HIP against the oracle:
+    iteration counts, status, rho, results, and the gait / S getters."""
+    import qrw_hip
+
+    N_gait = max(20, N + 4)
+    hand = _hand_tables(N, N_gait)
+    B = hand.shape[0]
+    sb = synth_mod.SyntheticBatch(B, N, N_gait=N_gait, gaits=("walk", "trot", "bounding"), seed0=20660000 + N)
+    eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
+    ref = oracle_mod.MPCBatch(B, 0.02, N, 0.02 * N, N_gait, fast=False)
+    refs1 = [oracle_mod.MPC(0.02, N, 0.02 * N, N_gait) for _ in range(B)]
+    for c in range(6):
+        d = sb.step(c)
+        fsteps = hand if c in (1, 2, 4) else d["fsteps"]
+        if c == 4:
+            fsteps = np.roll(hand, 1, axis=0)  # every instance meets another corner under a warm start
+        out = eng.mpc_solve_host(d["xref"], fsteps, c)
+        check_against_oracle(eng, ref, dict(xref=d["xref"], fsteps=fsteps), c, out)
+        for b in range(B):
+            assert refs1[b].run(c, d["xref"][b], fsteps[b]) == 0
+            gait, S = eng.mpc_gait(b)
+            assert np.array_equal(gait, refs1[b].get_gait()), (c, b)
+            assert np.array_equal(S, refs1[b].get_Sgait()), (c, b)
