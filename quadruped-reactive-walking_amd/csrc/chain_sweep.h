@@ -12,25 +12,19 @@ namespace qrw {
 // a chain.  ACROSS the two chains they are not: both chains are read by one instruction (chain A in DPP row 0, chain B in row 1,
 // i.e. lanes 0-15 / 16-31 of the same bank group: ds_read_b64 is served in two groups of 32 lanes, ds_read_b128 in four groups
 // of 16 -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 --, 64 banks of 4 bytes), and with the slot stride 168 every
-// sweep read is a 2-way conflict: SQ_LDS_BANK_CONFLICT is a third of the kernel's LDS-array cycles.
-// -DQRW_BANK_FREE_LAYOUT=1 (round 4, measured, NOT the default) removes them: chain B's slot must sit 32 banks from chain A's in
-// the forward sweep (slot distance m) and 0 banks in the backward sweep (slot distance m - 1), which a slot stride of 176
-// doubles (= 32 banks mod 64) and a gap of 16 doubles in front of chain B's slots give (even m; odd m: no gap); lanes 12-15 of
-// a row repeat an address of their own lane group.  Counters at batch 4096 (profiles/r4_pmc_lds_contention.txt):
-// SQ_LDS_BANK_CONFLICT 0.165 -> 0.029 of the wave cycles, SQ_LDS_IDX_ACTIVE 0.497 -> 0.362 -- and the launch time does not move
-// (677 k control steps/s either way): the LDS array is not what the four wavefronts of a compute unit compete for.  Not shipped:
-// it costs 1.1 KB of LDS per instance and the N = 32 instantiations a few dwords of scratch (their LDS struct exceeds 64 KB).
-#ifndef QRW_BANK_FREE_LAYOUT
-#define QRW_BANK_FREE_LAYOUT 0
-#endif
-constexpr int kCol = 14;                                  // column stride of a chain matrix in LDS
-constexpr int kSlot = QRW_BANK_FREE_LAYOUT ? 176 : 168;   // slot stride (12 * kCol = 168 used)
-__host__ __device__ constexpr int chain_gap(int m) { return (QRW_BANK_FREE_LAYOUT && !(m & 1)) ? 16 : 0; }  // doubles in front of chain B's slots
+// sweep read is a 2-way conflict: SQ_LDS_BANK_CONFLICT is a third of the kernel's LDS-array cycles.  A layout without them
+// (slot stride 176 and a gap of 16 doubles in front of chain B's slots) was measured in round 4: the conflicts go (0.165 ->
+// 0.029 of the wave cycles, profiles/r4_pmc_lds_contention.txt) and the launch time does not move (677 k control steps/s either
+// way), for 1.1 KB more LDS per instance and a few dwords of scratch in the N = 32 instantiations.  Not shipped; the variant is
+// scripts/experiments/slower_forms.patch (docs/HISTORY.md, round 4).  chain_gap / chain_slot are where it plugs in.
+constexpr int kCol = 14;    // column stride of a chain matrix in LDS
+constexpr int kSlot = 168;  // slot stride (12 * kCol)
+__host__ __device__ constexpr int chain_gap(int m) { return 0; }  // doubles in front of chain B's slots
 __host__ __device__ constexpr int chain_slot(int slot, int m) { return slot * kSlot + (slot >= m ? chain_gap(m) : 0); }
 // row whose transposed entries a lane reads in the backward sweep (lanes 12-15 have none)
 __device__ __forceinline__ int chain_row_t(int lane) {
   const int l = lane & 15;
-  return (l < 12) ? l : (QRW_BANK_FREE_LAYOUT ? l - 12 : 11);
+  return (l < 12) ? l : 11;
 }
 __host__ __device__ constexpr int chain_lds_doubles(int slots, int m) { return slots * kSlot + chain_gap(m); }
 
@@ -241,12 +235,9 @@ __device__ __forceinline__ void chain_forward(const double* sN, double* sX, doub
     const double* q = pm + (t - 1) * kSlot;
 #pragma unroll
     for (int c = 0; c < 12; c++) {
-#ifndef QRW_CHAIN_READ2
-      // relaxed atomic load: stays a ds_read_b64 (the merged ds_read2_b64 form takes twice as long per byte)
+      // relaxed atomic load: stays a ds_read_b64 (the merged ds_read2_b64 form a plain load compiles to takes twice as long
+      // per byte; that variant is in scripts/experiments/slower_forms.patch)
       b.m[c] = __hip_atomic_load(q + c * kCol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-      b.m[c] = q[c * kCol];
-#endif
     }
     b.r = px[t * 12];  // chain B, t = LB: position N (zeros); t > LB: unused
   };

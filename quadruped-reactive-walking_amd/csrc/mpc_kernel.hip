@@ -29,13 +29,8 @@
 #include <vector>
 
 #include "chain_sweep.h"
-#include "dissect.h"
 #include "qrw_device.h"
 #include "qrw_kernels.h"
-
-#ifndef QRW_N32_DISSECT
-#define QRW_N32_DISSECT 0
-#endif
 
 namespace qrw {
 
@@ -672,13 +667,7 @@ __device__ __forceinline__ void pre_end_chunk(const MpcArgs& a, int b, bool park
 template <int NW, bool FULL, bool SEQ, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   static_assert(!(SEQ && PRE), "one queueing mode at a time");
-  // N = 32, OPTIONAL (-DQRW_N32_DISSECT=1): the state system dissected around step 16 so that both wavefronts sweep their own
-  // half (dissect.h).  Parity-green with identical iteration counts, but measured SLOWER than the twisted form below (60 k
-  // against 75 k control steps/s at batch 4096, DESIGN.md 6b "round 3": the sweeps' 2.2 k clocks saved per iteration are
-  // outweighed by the fill products, the root solve and three workgroup barriers on the critical path), so it is off in the
-  // shipped build; the library's self-test keeps exercising its factorisation and solve (dissect_selftest).
-  constexpr bool DIS = (QRW_N32_DISSECT != 0) && (NW == 2 && FULL);
-  __shared__ std::conditional_t<DIS, MpcLdsDis, MpcLdsT<NW>> L;
+  __shared__ MpcLdsT<NW> L;
   constexpr int T = 64 * NW;  // threads per instance
   // longest-first scheduling: blocks are dealt to the CUs in index order, so block i takes the instance with the
   // i-th largest iteration count of the PREVIOUS solve (a good predictor: warm-started receding-horizon problems)
@@ -688,7 +677,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #ifdef QRW_DEBUG_POISON
   // diagnostic build (scripts/gpu_poison_bisect.py): one member of the LDS struct filled with NaN before anything else runs, the
   // member chosen by the otherwise unused pre_bin -- which unwritten LDS does a solve read?
-  if constexpr (!SEQ && !PRE && !DIS) {
+  if constexpr (!SEQ && !PRE) {
     const double qnan = __longlong_as_double(-1ll);
     auto fill = [&](double* p, int n) { for (int e = tid; e < n; e += 64 * NW) p[e] = qnan; };
     switch (a.pre_bin) {
@@ -753,27 +742,16 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
   const bool has_next = act && (k + 1 < N);
   const bool has_prev = act && (k > 0);
   // lane-constant coefficients that replace per-iteration selects (0/1 masks folded into the multipliers)
-  // (dissected N = 32: step 15's successor lives in the other wavefront; its terms enter the right-hand side through the
-  // boundary patch of the ADMM loop instead of the in-wavefront exchange)
-  const bool next_here = has_next && !((QRW_N32_DISSECT != 0) && NW == 2 && FULL && k == 15);
+  const bool next_here = has_next;
   const double mN = next_here ? 1.0 : 0.0, mN6 = (next_here && j >= 2) ? a.dt : 0.0;
   const double mP = has_prev ? 1.0 : 0.0, mP6 = (has_prev && j < 2) ? a.dt : 0.0;
   const double mG = (j >= 2) ? 1.0 : 0.0, mGN = (j >= 2 && next_here) ? 1.0 : 0.0;
   const int kp = has_prev ? k - 1 : k;
-  int kx, kpx;  // positions in sX
-  if constexpr (DIS) {
-    kx = dis_pos(k);
-    kpx = dis_pos(kp);
-    for (int e = tid; e < 36 * 12; e += T) L.sX[e] = 0.0;
-    for (int e = tid; e < kSlot; e += T) L.sN[kDisRightBase + e] = 0.0;
-    for (int e = tid; e < 15 * kFillStride + 144; e += T) L.sFill[e] = 0.0;
-    if (tid < 48) (&L.sEb[0][0])[tid] = 0.0;
-  } else {
-    kx = act ? chain_pos(k, N >> 1, N) : k;
-    kpx = act ? chain_pos(kp, N >> 1, N) : k;
-    if (tid < 24) L.sX[N * 12 + tid] = 0.0;
-    for (int e = tid; e < kSlot; e += T) L.sN[chain_slot(16 * NW - 1, N >> 1) + e] = 0.0;
-  }
+  // positions in sX
+  const int kx = act ? chain_pos(k, N >> 1, N) : k;
+  const int kpx = act ? chain_pos(kp, N >> 1, N) : k;
+  if (tid < 24) L.sX[N * 12 + tid] = 0.0;
+  for (int e = tid; e < kSlot; e += T) L.sN[chain_slot(16 * NW - 1, N >> 1) + e] = 0.0;
 
   // ---- constants (float literals promoted exactly as the reference does, MPC.cpp:17-29,330,346)
   const double dt = a.dt;
@@ -989,8 +967,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
     double nX[3], nF[3], nD[3], nS[3], nC[5];
     double EdL[3], EdA[3], mDf[3], mBD[3];
     double EnV[3], En6V[3], DxpV[3], Dxp6V[3];
-    if constexpr (DIS) { nb_next_dis(Ed, EnV, En6V, L.sEb[2], k, j, lane); nb_prev_dis(Dx0, DxpV, Dxp6V, L.sEb[3], k, j, lane); }
-    else { nb_next<NW, !FULL>(Ed, EnV, En6V, L.sE, k, j, lane, has_next); nb_prev<NW, !FULL>(Dx0, DxpV, Dxp6V, L.sE, k, j, lane, has_prev); }
+    nb_next<NW, !FULL>(Ed, EnV, En6V, L.sE, k, j, lane, has_next);
+    nb_prev<NW, !FULL>(Dx0, DxpV, Dxp6V, L.sE, k, j, lane, has_prev);
 #pragma unroll
     for (int t = 0; t < 3; t++) {
       const double En = EnV[t], En6 = En6V[t], Dxp = DxpV[t], Dxp6 = Dxp6V[t];
@@ -1210,9 +1188,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       wg_sync();
 #pragma unroll
       for (int c = 0; c < 6; c++) { Kr[0][c] = L.sW[k * kWSz + j * 6 + c]; Kr[1][c] = L.sW[k * kWSz + kr1 * 6 + c]; }
-      if constexpr (DIS) {
-        dis_factorize(L, dt, tid, k, j, [&](int t, int c, double v) { Di[t][c].set(v); });
-      } else {
+      {
         double DiV[3][12];
 #pragma unroll
         for (int t = 0; t < 3; t++)
@@ -1225,12 +1201,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
           for (int c = 0; c < 12; c++) Di[t][c].set(DiV[t][c]);
       }
       // wD was re-based above
-      if constexpr (DIS) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) { wnV[t] = shfl(wD[t], lane + 4); wn6V[t] = shfl(wD[t], lane + 2); }
-      } else {
-        nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
-      }
+      nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
     PH(0);
     }  // need_factor
 
@@ -1275,37 +1246,13 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
       double gsV[3], gnV[3], gdum[3];
 #pragma unroll
       for (int t = 0; t < 3; t++) gsV[t] = -((j == 3) ? yK[3 + t] : yK[t]);
-      if constexpr (DIS) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) gnV[t] = shfl(gsV[t], lane + 4);
-      } else {
-        nb_next<NW, !FULL>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
-      }
+      nb_next<NW, !FULL>(gsV, gnV, gdum, L.sE, k, j, lane, has_next);
 #pragma unroll
       for (int t = 0; t < 3; t++) rX[t] += mGN * gnV[t] - mG * gsV[t];
-      if constexpr (DIS) {
-        // boundary patch: what step 16 (wavefront 1) adds to step 15's right-hand side (wavefront 0) -- its wD (same foot, and
-        // dt times foot j - 2 on the velocity entries) and its force-elimination term -- through LDS, one workgroup barrier
-        if (k == 16) {
-#pragma unroll
-          for (int t = 0; t < 3; t++) { L.sEb[0][3 * j + t] = wD[t] + mG * gsV[t]; L.sEb[1][3 * j + t] = wD[t]; }
-        }
-        __syncthreads();
-        const double p6 = (j >= 2) ? dt : 0.0;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const double pa = L.sEb[0][3 * j + t], pb = L.sEb[1][3 * ((j + 2) & 3) + t];
-          rX[t] += (k == 15) ? pa + p6 * pb : 0.0;
-        }
-      }
     }
     PH(2);
     // ---- 3. block-tridiagonal solve (twisted block LDL', sweeps on the FP64 VALU with DPP row broadcasts)
-    if constexpr (DIS) {
-      dis_solve(L, rX, [&](int t, double (&dr)[12]) { AccD::get12(Di[t], dr); }, lane, wv, k, j, [&](int ph) {
-        if (ph == 3) { PH(3); } else if (ph == 4) { PH(4); } else { PH(5); }
-      });
-    } else {
+    {
       if (act) {
 #pragma unroll
         for (int t = 0; t < 3; t++) L.sX[kx * 12 + 3 * j + t] = rX[t];
@@ -1385,12 +1332,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
         wD[t] = act ? -thD[t] : 0.0;
         etS[t] = fma(aOS[t], fh[t], etS[t]);  // force-enable rows: z is identically 0 (l = u = 0)
       }
-      if constexpr (DIS) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) { wnV[t] = shfl(wD[t], lane + 4); wn6V[t] = shfl(wD[t], lane + 2); }
-      } else {
-        nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
-      }
+      nb_next<NW, !FULL>(wD, wnV, wn6V, L.sE, k, j, lane, has_next);
 #pragma unroll
       for (int c = 0; c < 5; c++) {
         const double s_ = fma(aOC[c], cv[c], (1.0 - alpha) * zeC[c]) + etC[c];
@@ -1487,7 +1429,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mpc_solve_kernel(MpcArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; t++) { eL[t] = quad_bcast<2>(eD[t]); eA[t] = quad_bcast<3>(eD[t]); }
         double enV[3], en6V[3];
-        if constexpr (DIS) nb_next_dis(eD, enV, en6V, L.sEb[2], k, j, lane); else nb_next<NW, !FULL>(eD, enV, en6V, L.sE, k, j, lane, has_next);
+        nb_next<NW, !FULL>(eD, enV, en6V, L.sE, k, j, lane, has_next);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
           const double en = enV[t], en6 = en6V[t];
@@ -1954,132 +1896,5 @@ int sweeps_selftest(double* max_err) {
       }
   if (max_err) *max_err = me;
   return (me < 1e-12) ? 0 : 1;
-}
-}  // namespace qrw
-
-// ---- self-test of the dissected solve (dissect.h): factorisation + solve of a synthetic 32-step system in the production LDS
-// layout, two right-hand sides one after the other (the second checks that a solve leaves the layout's zero vectors intact),
-// against a dense host solve of the same matrix ---------------------------------------------------------------------------
-namespace qrw {
-__global__ __launch_bounds__(128) void dissect_selftest_kernel(const double* om, const double* dg, const double* W, const double* r,
-                                                               double dt, double* x) {
-  __shared__ MpcLdsDis L;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int k = 16 * wv + (lane >> 2), j = lane & 3;
-  for (int e = tid; e < 36 * 12; e += 128) L.sX[e] = 0.0;
-  for (int e = tid; e < kSlot; e += 128) L.sN[kDisRightBase + e] = 0.0;
-  for (int e = tid; e < 15 * kFillStride + 144; e += 128) L.sFill[e] = 0.0;
-  if (tid < 48) (&L.sEb[0][0])[tid] = 0.0;
-  for (int e = tid; e < 32 * 12; e += 128) { L.sOm[e] = om[e]; L.sDg[e] = dg[e]; }
-  for (int e = tid; e < 32 * kDisWSz; e += 128) L.sW[e] = W[e];
-  __syncthreads();
-  double Di[3][12];
-#pragma unroll
-  for (int t = 0; t < 3; t++)
-#pragma unroll
-    for (int c = 0; c < 12; c++) Di[t][c] = 0.0;
-  dis_factorize(L, dt, tid, k, j, [&](int t, int c, double v) { Di[t][c] = v; });
-  for (int rhs = 0; rhs < 2; rhs++) {
-    double rX[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) rX[t] = r[rhs * 384 + k * 12 + 3 * j + t];
-    dis_solve(L, rX, [&](int t, double (&dr)[12]) {
-#pragma unroll
-      for (int c = 0; c < 12; c++) dr[c] = Di[t][c];
-    }, lane, wv, k, j, [](int) {});
-#pragma unroll
-    for (int t = 0; t < 3; t++) x[rhs * 384 + k * 12 + 3 * j + t] = L.sX[dis_pos(k) * 12 + 3 * j + t];
-    __syncthreads();
-  }
-}
-
-int dissect_selftest(double* max_err) {
-  constexpr int N = 32, n = 12, D = N * n;
-  const double dt = 0.02;
-  // (heap, not function-static: concurrent callers must not share them)
-  std::vector<double> omv(N * 12), dgv(N * 12), Wv(N * 36), rv(2 * D), xdv(2 * D), Kv((size_t)D * D), rhsv(2 * D);
-  double *om = omv.data(), *dg = dgv.data(), *W = Wv.data(), *r = rv.data(), *xd = xdv.data(), *K = Kv.data();
-  double (*rhs)[D] = reinterpret_cast<double (*)[D]>(rhsv.data());
-  // synthetic data with the kernel's structure and spread of magnitudes: omega_D of the dynamics rows, K^-1 blocks, cost diagonal
-  for (int k = 0; k < N; k++) {
-    for (int i = 0; i < 12; i++) {
-      om[k * 12 + i] = 40.0 + 30.0 * sin(0.7 * (k * 12 + i) + 0.3);
-      dg[k * 12 + i] = 0.05 + 0.04 * cos(1.3 * (k * 12 + i));
-    }
-    double A[36];
-    for (int a = 0; a < 36; a++) A[a] = sin(0.91 * (k * 36 + a) + 0.5);
-    for (int a = 0; a < 6; a++)
-      for (int b = 0; b < 6; b++) {
-        double s = (a == b) ? 25.0 : 0.0;
-        for (int c = 0; c < 6; c++) s += 4.0 * A[a * 6 + c] * A[b * 6 + c];
-        W[k * 36 + a * 6 + b] = s;
-      }
-  }
-  for (int e = 0; e < 2 * D; e++) r[e] = cos(0.37 * e) + 0.25 * sin(0.011 * e * e);
-  // dense assembly: K = sum_k M_k' Om_k M_k + diag(dg), M_k = [A_d on step k-1, -I on step k], Om_k = blkdiag(om_k[0..5], W_k)
-  for (size_t e = 0; e < (size_t)D * D; e++) K[e] = 0.0;
-  auto Kat = [&](int k1, int i1, int k2, int i2) -> double& { return K[(size_t)(k1 * n + i1) * D + (k2 * n + i2)]; };
-  for (int k = 0; k < N; k++) {
-    for (int i = 0; i < 12; i++) Kat(k, i, k, i) += dg[k * 12 + i];
-    for (int i = 0; i < 6; i++) Kat(k, i, k, i) += om[k * 12 + i];
-    for (int a = 0; a < 6; a++)
-      for (int b = 0; b < 6; b++) Kat(k, 6 + a, k, 6 + b) += W[k * 36 + a * 6 + b];
-    if (k > 0) {
-      const int p = k - 1;
-      for (int i = 0; i < 6; i++) {
-        const double o = om[k * 12 + i];
-        Kat(p, i, p, i) += o; Kat(p, i, p, i + 6) += dt * o; Kat(p, i + 6, p, i) += dt * o; Kat(p, i + 6, p, i + 6) += dt * dt * o;
-        Kat(k, i, p, i) -= o; Kat(k, i, p, i + 6) -= dt * o; Kat(p, i, k, i) -= o; Kat(p, i + 6, k, i) -= dt * o;
-      }
-      for (int a = 0; a < 6; a++)
-        for (int b = 0; b < 6; b++) {
-          const double w = W[k * 36 + a * 6 + b];
-          Kat(p, 6 + a, p, 6 + b) += w; Kat(k, 6 + a, p, 6 + b) -= w; Kat(p, 6 + b, k, 6 + a) -= w;
-        }
-    }
-  }
-  for (int q = 0; q < 2; q++) for (int e = 0; e < D; e++) rhs[q][e] = r[q * D + e];
-  // Gaussian elimination with partial pivoting on [K | rhs0 rhs1]
-  for (int c = 0; c < D; c++) {
-    int piv = c;
-    for (int rr = c + 1; rr < D; rr++) if (fabs(K[(size_t)rr * D + c]) > fabs(K[(size_t)piv * D + c])) piv = rr;
-    if (piv != c) {
-      for (int cc = 0; cc < D; cc++) { const double t_ = K[(size_t)c * D + cc]; K[(size_t)c * D + cc] = K[(size_t)piv * D + cc]; K[(size_t)piv * D + cc] = t_; }
-      for (int q = 0; q < 2; q++) { const double t_ = rhs[q][c]; rhs[q][c] = rhs[q][piv]; rhs[q][piv] = t_; }
-    }
-    const double d = 1.0 / K[(size_t)c * D + c];
-    for (int rr = c + 1; rr < D; rr++) {
-      const double f = K[(size_t)rr * D + c] * d;
-      if (f == 0.0) continue;
-      for (int cc = c; cc < D; cc++) K[(size_t)rr * D + cc] -= f * K[(size_t)c * D + cc];
-      for (int q = 0; q < 2; q++) rhs[q][rr] -= f * rhs[q][c];
-    }
-  }
-  for (int q = 0; q < 2; q++)
-    for (int c = D - 1; c >= 0; c--) {
-      double s_ = rhs[q][c];
-      for (int cc = c + 1; cc < D; cc++) s_ -= K[(size_t)c * D + cc] * rhs[q][cc];
-      rhs[q][c] = s_ / K[(size_t)c * D + c];
-    }
-  SelfTestBuf bom, bdg, bW, br, bx;
-  SelfTestStream st;
-  const size_t n12 = omv.size() * sizeof(double), nW = Wv.size() * sizeof(double), n2D = rv.size() * sizeof(double);
-  if (!bom.alloc(n12) || !bdg.alloc(n12) || !bW.alloc(nW) || !br.alloc(n2D) || !bx.alloc(n2D) || !st.create()) return -1;
-  hipMemcpyAsync(bom.p, om, n12, hipMemcpyHostToDevice, st.s); hipMemcpyAsync(bdg.p, dg, n12, hipMemcpyHostToDevice, st.s);
-  hipMemcpyAsync(bW.p, W, nW, hipMemcpyHostToDevice, st.s); hipMemcpyAsync(br.p, r, n2D, hipMemcpyHostToDevice, st.s);
-  hipMemsetAsync(bx.p, 0xFF, n2D, st.s);
-  hipLaunchKernelGGL(dissect_selftest_kernel, dim3(1), dim3(128), 0, st.s, bom.as<double>(), bdg.as<double>(), bW.as<double>(), br.as<double>(),
-                     dt, bx.as<double>());
-  hipMemcpyAsync(xd, bx.p, n2D, hipMemcpyDeviceToHost, st.s);
-  if (hipStreamSynchronize(st.s) != hipSuccess) return -2;
-  double me = 0.0, scale = 0.0;
-  for (int q = 0; q < 2; q++) for (int c = 0; c < D; c++) scale = fmax(scale, fabs(rhs[q][c]));
-  for (int q = 0; q < 2; q++)
-    for (int c = 0; c < D; c++) {
-      const double d = fabs(xd[q * D + c] - rhs[q][c]) / scale;
-      me = fmax(me, (d == d) ? d : 1e300);
-    }
-  if (max_err) *max_err = me;
-  return (me < 1e-10) ? 0 : 1;
 }
 }  // namespace qrw

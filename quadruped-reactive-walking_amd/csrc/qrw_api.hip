@@ -1032,14 +1032,6 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
   std::lock_guard<std::mutex> lock(g_kat_mutex);  // one self-test at a time (qrw_create's known-answer check takes the same lock)
   const int rc = qrw::sweeps_selftest(max_err);
   if (rc != 0) return rc;
-  double derr = 0.0;
-  const int drc = qrw::dissect_selftest(&derr);  // the N = 32 path: two-half factorisation with fill, root, both sweeps
-  if (drc != 0) {
-    char msg[200];
-    snprintf(msg, sizeof(msg), "qrw_selftest_sweeps: dissected N = 32 solve differs from the dense host solve (rc %d, relative error %.3g)", drc, derr);
-    return fail(3, msg);
-  }
-  if (max_err && derr > *max_err) *max_err = derr;
   // the whole solve, not only its sweeps: every instantiation of mpc_solve_kernel (compile-time and runtime horizon, one and two
   // wavefronts, one launch per call / time-sliced / sequence)
   static const int kat_cases[][2] = {{16, kKatPlain}, {12, kKatPlain}, {32, kKatPlain}, {24, kKatPlain}, {32, kKatSliced}, {24, kKatSliced},

@@ -102,17 +102,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // A double parked in two accumulation registers (gfx950: 256 AGPRs beside the 256 architectural VGPRs; VALU
 // instructions cannot read them, one v_accvgpr_read per half brings the value back).
-#ifdef QRW_NO_ACCD  // diagnostic: plain registers, allocation left to the compiler
-struct AccD {
-  double v_;
-  __device__ __forceinline__ void set(double v) { v_ = v; }
-  __device__ __forceinline__ double get() const { return v_; }
-  static __device__ __forceinline__ void get12(const AccD (&a)[12], double (&v)[12]) {
-#pragma unroll
-    for (int c = 0; c < 12; c++) v[c] = a[c].v_;
-  }
-};
-#else
+// (plain registers instead, allocation left to the compiler: scripts/experiments/slower_forms.patch)
 struct AccD {
   int lo, hi;
   __device__ __forceinline__ void set(double v) {
@@ -145,8 +135,6 @@ struct AccD {
     return __hiloint2double(h, l);
   }
 };
-
-#endif
 
 // Reciprocal from the hardware estimate and two Newton steps (<= 1 ulp for the well-scaled positive values it is used
 // on: pivots, scalings, rho) -- a quarter of the instructions of the IEEE division sequence.

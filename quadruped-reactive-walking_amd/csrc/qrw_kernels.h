@@ -145,7 +145,6 @@ int pinv6_launch(const double* d_M18, double* d_Yinv, int B, hipStream_t stream)
 
 namespace qrw {
 int sweeps_selftest(double* max_err);
-int dissect_selftest(double* max_err);  // N = 32 dissected factorisation + solve against a dense host solve
 
 // ---- planners (planner_kernel.hip)
 enum PlannerMode { kPlanInit = 1, kPlanGait = 2, kPlanFootsteps = 4, kPlanTraj = 8, kPlanState = 16, kPlanOutputs = 32 };

@@ -1,7 +1,8 @@
-"""The algebra of csrc/dissect.h (the optional N = 32 path: the horizon dissected around step 16, both halves swept as
-16-step twisted systems, the coupling carried as fill blocks E_k and one root solve) restated in numpy on a random
-symmetric positive definite block-tridiagonal system and checked against a dense solve.  CPU only; the HIP code itself
-is checked on the GPU by the library's self-test (qrw_selftest_sweeps -> dissect_selftest) against a dense host solve."""
+"""The algebra of dissect.h (a measured-slower form of the N = 32 path, kept as scripts/experiments/slower_forms.patch: the
+horizon dissected around step 16, both halves swept as 16-step twisted systems, the coupling carried as fill blocks E_k
+and one root solve) restated in numpy on a random symmetric positive definite block-tridiagonal system and checked
+against a dense solve.  CPU only (python -m pytest scripts/experiments/dissection_algebra_check.py); the HIP code is
+checked on the GPU by the patched library's self-test (qrw_selftest_sweeps -> dissect_selftest) against a dense host solve."""
 import numpy as np
 
 

@@ -1,5 +1,7 @@
 #!/bin/bash
-# On the GPU box: the dissected N = 32 path -- linear-algebra self-test first, then the N = 32 parity tests, then timing.
+# On the GPU box: the dissected N = 32 path (a measured-slower form, NOT in csrc/: build it first with
+#   scripts/experiments/build_slower_form.sh dissect "-DQRW_N32_DISSECT=1"   and run this with QRW_HIP_LIB=build/libqrw_hip_dissect.so)
+# -- linear-algebra self-test first, then the N = 32 parity tests, then timing.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out

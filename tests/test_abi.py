@@ -40,28 +40,34 @@ def test_header_and_binding_agree(lib):
         assert hasattr(lib, name), name
 
 
-def test_shipped_sources_hold_no_wrong_result_paths(tmp_path):
-    """The timing experiments that compute wrong results on purpose (what a re-arrangement of the sweeps could gain at most) are
-    NOT in the translation units of libqrw_hip.so: they live in scripts/experiments/timing_experiments.patch, applied to a copy of
-    the sources by scripts/experiments/build_timing_experiment.sh, whose output's name the loader refuses.  The patch must still
-    apply to today's sources (otherwise the recorded experiments cannot be repeated)."""
+def test_shipped_sources_hold_no_experiment_paths(tmp_path):
+    """What lost its A/B is NOT in the translation units of libqrw_hip.so.  The timing experiments that compute wrong results on
+    purpose (what a re-arrangement of the sweeps could gain at most) live in scripts/experiments/timing_experiments.patch, applied
+    to a copy of the sources by build_timing_experiment.sh, whose output's name the loader refuses; the parity-green forms that
+    measured slower (the dissected N = 32 solve with its self-test, the conflict-free LDS layout, plain sweep loads, compiler-
+    allocated Delta^-1 rows) live in slower_forms.patch / build_slower_form.sh.  Both patches must still
+    apply to today's sources, without fuzz (otherwise the recorded experiments cannot be repeated)."""
     import shutil
     import subprocess
 
     csrc = os.path.join(ROOT, "quadruped-reactive-walking_amd", "csrc")
     for f in os.listdir(csrc):
         if f.endswith((".h", ".hip")) or f == "Makefile":
-            assert "EXPERIMENT" not in open(os.path.join(csrc, f)).read(), f
+            text = open(os.path.join(csrc, f)).read()
+            for word in ("EXPERIMENT", "QRW_N32_DISSECT", "BANK_FREE", "CHAIN_READ2", "QRW_NO_ACCD", "dissect_selftest"):
+                assert word not in text, (f, word)
+    assert not os.path.exists(os.path.join(csrc, "dissect.h"))
     if shutil.which("patch") is None:
         pytest.skip("patch not available")
-    work = tmp_path / "csrc"
-    work.mkdir()
-    for f in os.listdir(csrc):
-        if f.endswith((".h", ".hip")):
-            shutil.copy(os.path.join(csrc, f), work / f)
-    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "scripts", "experiments", "timing_experiments.patch")],
-                       cwd=work, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-1500:]
+    for name in ("timing_experiments.patch", "slower_forms.patch"):
+        work = tmp_path / name.split(".")[0]
+        work.mkdir()
+        for f in os.listdir(csrc):
+            if f.endswith((".h", ".hip")):
+                shutil.copy(os.path.join(csrc, f), work / f)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-F", "0", "-i", os.path.join(ROOT, "scripts", "experiments", name)],
+                           cwd=work, capture_output=True, text=True)
+        assert r.returncode == 0 and "fuzz" not in r.stdout, (name, r.stdout[-1500:])
 
 
 def test_loader_refuses_a_wrong_results_build(tmp_path, monkeypatch):
