@@ -380,8 +380,11 @@ def main():
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
             # 32 compute units for the loop's stream: the highest free-running rate, paid for in iteration latency
             out["secondary_ratio_1_10_async_32cu"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True, loop_cus=32)
-            # what Controller_batch(B, ...) builds without arguments at this fleet size (two staggered stream groups, joined per iteration)
-            out["secondary_ratio_1_10_default_object"] = device_resident_loop(sb, B, N, N_gait, dev, groups=None)
+            # two staggered stream groups through compute() (joined on the caller's stream every iteration): what
+            # Controller_batch.for_deadline builds for fleets of 1025..2048 robots; opt-in (the default object is one handle:
+            # secondary_ratio_1_10 above)
+            if B % 2 == 0:
+                out["secondary_ratio_1_10_two_groups_staggered_joined"] = device_resident_loop(sb, B, N, N_gait, dev, groups=2, stagger=True)
             if (N, gaits) == (16, ("trot",)):
                 out["realtime_slot"] = realtime_slot_leg(sb, N, N_gait, dev)
         if not args.no_configs and not args.no_secondary and (B, N, gaits) == (4096, 16, ("trot",)):
@@ -942,7 +945,8 @@ def device_resident_loop(sb, B, N, N_gait, dev, iters=40, k_mpc=10, multiprocess
 def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 2048, 4096)):
     """How many robots fit the reference's real-time slot: the 1:10 loop (scripts/Controller.py:246, dt_wbc = 2 ms,
     src/config_solo12.yaml:6) paced at 2 ms for a growing fleet, in the synchronous mode (the iteration that solves carries the
-    whole MPC launch), as the default object builds it (two staggered stream groups from 2048 robots on) and in the asynchronous
+    whole MPC launch; this is the default object), as two / four staggered stream groups (opt-in, what Controller_batch.for_deadline
+    builds between 1025 and 2048 robots) and in the asynchronous
     mode (the solve on its own compute units; the caller on the loop's stream): median / worst time from the call of compute() to
     its PD targets being ready, host time of a compute() that does not solve, and the largest fleet whose WORST iteration stays
     inside the slot."""
@@ -952,11 +956,11 @@ def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 2048, 409
     for B in batches:
         sb = sb_full if B == sb_full.B else synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=("trot",), n_seq=1)
         row = {"batch": B}
-        for name, kw in (("sync", dict(groups=1)), ("default_object", dict(groups=None)),
+        for name, kw in (("sync", dict(groups=1)), ("two_staggered_groups", dict(groups=2, stagger=True)),
                          ("four_staggered_groups", dict(groups=4, stagger=True)),
                          ("async", dict(groups=1, multiprocessing=True, on_loop_stream=True))):
-            if name == "default_object" and B < 2048:
-                continue  # (the default object IS the single handle below 2048 robots)
+            if name == "two_staggered_groups" and B < 2048:
+                continue  # (one handle fits the slot there)
             if name == "four_staggered_groups" and B < 4096:
                 continue  # (only where two groups no longer fit the slot)
             r = device_resident_loop(sb, B, N, N_gait, dev, **kw)
@@ -965,13 +969,14 @@ def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 2048, 409
                          "free_running_M_iterations_per_s": r["value"] / 1e6, "stopped": r["instances_in_security_stop"]}
         rows.append(row)
     fits = {}
-    for name in ("sync", "default_object", "async"):
-        ok = [r["batch"] for r in rows if (name in r or (name == "default_object" and "sync" in r))
-              and (r.get(name) or r["sync"])["paced_worst_ms"] < 2.0]
+    for name in ("sync", "two_staggered_groups", "four_staggered_groups", "async"):
+        ok = [r["batch"] for r in rows if name in r and r[name]["paced_worst_ms"] < 2.0]
         fits[name] = max(ok) if ok else None
-    ok = [r["batch"] for r in rows if "four_staggered_groups" in r and r["four_staggered_groups"]["paced_worst_ms"] < 2.0]
-    fits["four_staggered_groups"] = max(ok) if ok else None
+    import Controller
+
+    fits["default_object"] = fits["sync"]  # Controller_batch(B, ...) without arguments is the single handle at every fleet size
     return {"slot_ms": 2.0, "k_mpc": 10, "rows": rows, "largest_batch_with_worst_iteration_inside_the_slot": fits,
+            "table_shipped_in_Controller.recommended_mode": dict(Controller.REALTIME_SLOT_FITS),
             "what": "1:10 control loop paced at dt_wbc = 2 ms, 40 paced iterations (4 of them solve) after 20 warm-up and 40 free-running "
                     "ones -- the loop's first two solves (QP set-up, cold start: about twice as many ADMM iterations) are not in the figure, "
                     "as the reference's first iterations would not be; latency = compute() call until the iteration's PD targets are ready (incl. the two copies that stand in for "

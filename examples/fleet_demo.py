@@ -25,8 +25,11 @@ dev = torch.device("cuda", 0)
 q_init = np.array([0.0, 0.7, -1.4, -0.0, 0.7, -1.4, 0.0, -0.7, +1.4, -0.0, -0.7, +1.4])  # scripts/main_solo12_control.py:120
 
 with torch.cuda.stream(torch.cuda.Stream(dev)):  # (keep the caller's work off the legacy default stream)
-    # groups: chosen from the fleet size (one handle below 2048 robots, two staggered stream groups from there)
-    ctl = Controller_batch(B, q_init, multiprocessing=(mode == "async"))
+    # "auto": the cheapest mode whose worst iteration fits the 2 ms slot (Controller.recommended_mode: one handle up to 1024
+    # robots, two staggered stream groups up to 2048, asynchronous MPC above); "sync" / "async": one handle either way.
+    # deadline=0.002 arms the monitor: a RuntimeWarning the first time an iteration takes longer on the device
+    ctl = (Controller_batch.for_deadline(B, q_init) if mode == "auto" else
+           Controller_batch(B, q_init, multiprocessing=(mode == "async"), deadline=0.002))
     # a caller that works on the loop's own stream saves compute() the hand-over between two streams (asynchronous single handle)
     ctx = torch.cuda.stream(ctl.loop_stream if ctl.loop_stream is not None else torch.cuda.current_stream())
     with ctx:

@@ -20,21 +20,37 @@ class Result:
         self.P, self.D, self.q_des, self.v_des, self.tau_ff = (t[:, i] for i in range(5))
 
 
-AUTO_GROUPS_MIN_BATCH = 2048  # from this fleet size on, groups=None means two stream groups (below: one handle)
+# Largest fleet whose WORST paced control iteration (the one that carries the MPC solve) stays inside the reference's 2 ms slot
+# (dt_wbc, /root/reference/src/config_solo12.yaml:6), per mode -- measured on one MI355X, horizon 16, k_mpc 10 (bench.py
+# `realtime_slot`, BENCH_r05 / profiles/r6_bench_line.json): synchronous single handle 5.6 ms at 4096 robots, two staggered
+# stream groups 3.2 ms, asynchronous MPC 0.24 ms.
+REALTIME_SLOT_FITS = (("sync", 1024), ("staggered_groups", 2048), ("async", 4096))
+REALTIME_SLOT_MEASURED_AT = 0.002
+
+
+def recommended_mode(batch, deadline=REALTIME_SLOT_MEASURED_AT):
+    """Constructor arguments of the cheapest mode whose worst iteration is expected to fit `deadline` seconds at this fleet size:
+    {} (synchronous, one handle: every robot steps on every tick, the reference loop), dict(groups=2, stagger=True) (half the
+    fleet runs k_mpc / 2 ticks behind the other half) or dict(multiprocessing=True) (the reference's asynchronous MPC: the
+    solve is off the tick and its result is adopted when it is there).  From REALTIME_SLOT_FITS, scaled linearly in the deadline
+    (the worst iteration is a whole MPC launch, proportional to the fleet from ~1000 robots on); None if no mode is expected to
+    fit (shard the fleet over more GPUs, sharding.py)."""
+    scale = float(deadline) / REALTIME_SLOT_MEASURED_AT
+    for mode, fits in REALTIME_SLOT_FITS:
+        if int(batch) <= fits * scale and not (mode == "staggered_groups" and int(batch) % 2):
+            return {"sync": {}, "staggered_groups": dict(groups=2, stagger=True), "async": dict(multiprocessing=True)}[mode]
+    return None
 
 
 def auto_groups(batch, groups=None, multiprocessing=False):
-    """Number of stream groups a fleet of `batch` robots is stepped as when the caller does not say: robots are independent
-    (SURVEY.md 8(e)), a launch of the MPC ends with its longest solve while most of the chip is already idle, and from about
-    2048 robots on two groups in flight fill that tail (+10 % control steps/s at batch 4096; in the 1:10 loop, staggered,
-    the worst iteration of the fleet takes 3.2 instead of 5.6 ms).  Below that one handle is the faster form -- and so it is in
-    the asynchronous mode at any size: the solve is off the tick there anyway, and every group would bring its own pair of
-    compute-unit-masked streams (measured at 4096 robots: 0.32 ms median tick as two asynchronous groups, 0.10 ms as one handle)."""
-    if groups is not None:
-        return int(groups)
-    if multiprocessing:
-        return 1
-    return 2 if (int(batch) >= AUTO_GROUPS_MIN_BATCH and int(batch) % 2 == 0) else 1
+    """Number of stream groups a fleet is stepped as: what the caller says, ONE handle otherwise -- every robot steps on every
+    tick and self.k is every robot's clock, as in the reference loop (scripts/Controller.py:200-326).  Stream groups are opt-in:
+    unstaggered they are bit-identical to one handle but slower in the 1:10 loop (twice the launches: 10.0 M against 12.4 M
+    iterations/s at 4096 robots), staggered they halve the fleet's worst iteration (3.2 against 5.6 ms) at the price of half the
+    fleet running k_mpc / 2 ticks behind -- a change of behaviour a caller has to ask for (recommended_mode / for_deadline say
+    when).  (Rounds 4-5 chose two staggered groups by themselves from 2048 robots on; ADVICE r5: discontinuous in the fleet
+    size and not the reference's loop.)"""
+    return int(groups) if groups is not None else 1
 
 
 class Controller_batch:
@@ -47,21 +63,27 @@ class Controller_batch:
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
-                 stagger=None, _out_views=None):
+                 stagger=None, deadline=None, _out_views=None):
         """q_init: (12,) or (B,12) initial joint angles (Controller.__init__ q_init, scripts/Controller.py:60).
 
-        groups: None = chosen from the fleet size (auto_groups: one handle below 2048 robots, two staggered stream groups from
-        there; always one handle in the asynchronous mode); 1 = one handle; G > 1 = the fleet as G stream groups
-        (Controller_groups).  Every robot's results are the single handle's, bit for bit.  Measured at batch 4096 in the 1:10 loop:
-        two groups joined on the caller's stream every iteration and NOT staggered run at 10.0 M iterations/s against 12.4 M for
-        the single handle (twice the launches) with the same worst iteration (5.6 ms, the one that carries the solve) -- which is
-        why automatically chosen groups are staggered: the worst iteration of the fleet drops to 3.1 ms, and 2048 robots fit the
-        reference's 2 ms slot where one handle fits 1024 (bench.py, realtime_slot).
+        groups: None or 1 = one handle (the default at every fleet size); G > 1 = the fleet as G stream groups
+        (Controller_groups).  Unstaggered, every robot's results are the single handle's, bit for bit.  Measured at batch 4096 in
+        the 1:10 loop: two groups joined on the caller's stream every iteration and NOT staggered run at 10.0 M iterations/s
+        against 12.4 M for the single handle (twice the launches) with the same worst iteration (5.6 ms, the one that carries
+        the solve); staggered, the worst iteration of the fleet drops to 3.1 ms, and 2048 robots fit the reference's 2 ms slot
+        where one handle fits 1024 (bench.py, realtime_slot).
 
-        stagger (groups > 1 only; None = True when the groups were chosen automatically, False when `groups` was given):
-        group g starts g * k_mpc / groups fleet ticks late, so the groups' MPC solves fall on different ticks and one
-        group's solve runs beside the other's plain iterations (Controller_groups).  Until a group has started its robots are
-        commanded to hold q_init (Result: P 3, D 0.2, q_des = q_init, zero v_des and tau_ff).
+        stagger (groups > 1 only, default False): group g starts g * k_mpc / groups fleet ticks late, so the groups' MPC solves
+        fall on different ticks and one group's solve runs beside the other's plain iterations (Controller_groups).  THIS CHANGES
+        WHAT THE ROBOTS DO: a robot of group g runs the single-handle controller started lag_of(g) ticks late -- at fleet tick t
+        it returns its iteration t - lag_of(g) --, and until then it is commanded to hold q_init (Result: P 3, D 0.2, q_des =
+        q_init, zero v_des and tau_ff); self.k is group 0's clock.
+
+        deadline (seconds, e.g. dt_wbc; None = no monitor): every compute() is bracketed by two events on the caller's stream and
+        the device time of finished iterations is read back without synchronising; the first time one exceeds the deadline a
+        RuntimeWarning names the measured worst case and the mode recommended_mode() would pick (the first 2 k_mpc iterations --
+        QP set-up and cold start of the first two solves -- are start-up and not accounted).  `overrun` holds
+        (worst seconds, iteration) from then on.  Controller_batch.for_deadline(...) builds that mode in the first place.
 
         multiprocessing=True mirrors the reference's asynchronous MPC (scripts/MPC_Wrapper.py:150-298, a child process
         on its own core polled through a shared flag) with HIP streams: the MPC solves on a stream restricted to all
@@ -108,6 +130,7 @@ class Controller_batch:
                 self._res = dict(result=_out_views["result"], error_flag=_out_views["error_flag"])
         self.multiprocessing = bool(multiprocessing)
         self.mpc_lag = mpc_lag
+        self._init_deadline(deadline)
         self.wbc_lanes = 16  # lanes per robot of the full WBC step (qrw_wbc_set_lanes): wbc16_kernel unless chosen otherwise below
         if self.multiprocessing:
             n_cu = qrw_hip.device_cu_count(device)
@@ -135,9 +158,79 @@ class Controller_batch:
             self._pending = []          # [(solve index, iteration it was issued at)] not adopted yet
             self._adopted = None        # index (mod 3) of the buffer the loop currently reads
 
+    @classmethod
+    def for_deadline(cls, batch, q_init, deadline=None, dt_wbc=0.002, **kw):
+        """The fleet in the cheapest mode whose worst iteration is expected inside `deadline` seconds (default: dt_wbc, the
+        slot the reference loop runs in, src/config_solo12.yaml:6) -- recommended_mode(): synchronous up to 1024 robots, two
+        staggered stream groups up to 2048, asynchronous MPC above (measured at 2 ms) --, with the deadline monitor armed."""
+        deadline = float(dt_wbc if deadline is None else deadline)
+        mode = recommended_mode(batch, deadline)
+        if mode is None:
+            raise qrw_hip.QrwError("no mode of one GPU has been measured to step %d robots inside %.3g s: shard the fleet (sharding.py)"
+                                   % (batch, deadline))
+        return Controller_batch(batch, q_init, dt_wbc=dt_wbc, deadline=deadline, **dict(mode, **kw))
+
+    # ---- deadline monitor (deadline=...): device time of every iteration, read back without synchronising
+    def _init_deadline(self, deadline):
+        self.deadline = None if deadline is None else float(deadline)
+        self.overrun = None        # (worst seconds, iteration) once an iteration exceeded the deadline
+        self.worst_iteration = 0.0  # worst measured so far (seconds; finished iterations only)
+        self._dl_pairs = []
+        # iterations before this one are not accounted: the loop's first two solves (QP set-up, cold start) are start-up, as the
+        # reference's own first iterations are (OSQP set-up inside the first MPC call, scripts/MPC_Wrapper.py:128-148)
+        self._dl_skip = 2 * self.k_mpc + max(getattr(self, "_delay", [0]))
+
+    def _deadline_begin(self):
+        torch = self._torch
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), self.k)
+        ev[0].record(torch.cuda.current_stream(self.dev))
+        return ev
+
+    def _deadline_end(self, ev):
+        ev[1].record(self._torch.cuda.current_stream(self.dev))
+        self._dl_pairs.append(ev)
+        self._deadline_account()
+
+    def _deadline_account(self):
+        while self._dl_pairs and self._dl_pairs[0][1].query():
+            a, b, k = self._dl_pairs.pop(0)
+            if k < self._dl_skip:
+                continue  # start-up: the first two solves of every robot set the QP up and start cold (about twice the ADMM iterations)
+            t = a.elapsed_time(b) * 1e-3
+            if t > self.worst_iteration:
+                self.worst_iteration = t
+            if t > self.deadline and (self.overrun is None or t > self.overrun[0]):
+                first = self.overrun is None
+                self.overrun = (t, k)
+                if first:
+                    import warnings
+
+                    rec = recommended_mode(self.B, self.deadline)
+                    how = ("more GPUs (sharding.py)" if rec is None else
+                           "Controller_batch(..., %s)" % ", ".join("%s=%r" % kv for kv in rec.items()) if rec else
+                           "this mode (is the device shared?)")
+                    warnings.warn("control iteration %d of %d robots took %.2f ms on the device, deadline %.2f ms (the iterations "
+                                  "that carry the MPC solve are the long ones); recommended for this fleet and deadline: %s"
+                                  % (k, self.B, t * 1e3, self.deadline * 1e3, how), RuntimeWarning, stacklevel=4)
+
+    def deadline_flush(self):
+        """Wait for the iterations issued so far and account them; returns the worst iteration's device time (seconds)."""
+        if self.deadline is not None and self._dl_pairs:
+            self._dl_pairs[-1][1].synchronize()
+            self._deadline_account()
+        return self.worst_iteration
+
     def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
         """One control iteration for every instance. All arguments CUDA float64 with leading dimension B:
         joy_v_ref (B,6), q_filt (B,19), v_filt (B,18), rpy (B,3), v_secu (B,12). Returns the Result views."""
+        if self.deadline is not None:
+            ev = self._deadline_begin()
+            r = self._compute_any(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+            self._deadline_end(ev)
+            return r
+        return self._compute_any(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+
+    def _compute_any(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
         if not self.multiprocessing:
             return self._compute(joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
         torch = self._torch
@@ -277,16 +370,23 @@ class Controller_batch:
     def _nonsolve_fast(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code, stream):
         """An iteration that does not solve, through the buffers bound in the library (qrw_hip.Batch.bind_iteration: the same two
         launches as control_pre + wbc_compute_result, one foreign call).  False until both calls have run once the ordinary way.
-        Bound again whenever the caller comes with other tensor objects than last time (a loop passes the same ones every tick)."""
+        Bound again whenever the caller comes with other tensor objects -- or the same objects on other storage -- than last time
+        (a loop passes the same ones every tick; the check is one data_ptr() per input tensor)."""
         if self._pre is None or self._post is None or self.result is None:
             return False
         fast = self._fast
+        ins = (joy_v_ref, q_filt, v_filt, rpy, v_secu)
         if (fast is None or fast[1] is not self._pre or fast[2] is not self._post or fast[3] is not stream
                 or fast[4] is not joy_v_ref or fast[5] is not q_filt or fast[6] is not v_filt or fast[7] is not rpy
                 or fast[8] is not v_secu
-                or not (fast[9] is joystick_code or (isinstance(joystick_code, int) and fast[9] == joystick_code))):
+                or not (fast[9] is joystick_code or (isinstance(joystick_code, int) and fast[9] == joystick_code))
+                # the same tensor OBJECTS on other storage (t.data = ..., set_(), resize_()): the bound pointers would be stale
+                or fast[10] != tuple(t.data_ptr() for t in ins)
+                or (fast[11] is not None and fast[11] != joystick_code.data_ptr())):
             step = self._b.bind_iteration(self._pre, self._post, (joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code), stream)
-            self._fast = fast = (step, self._pre, self._post, stream, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code)
+            self._fast = fast = (step, self._pre, self._post, stream, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code,
+                                 tuple(t.data_ptr() for t in ins),
+                                 joystick_code.data_ptr() if self._torch.is_tensor(joystick_code) else None)
         k = self.k
         self._pick_mpc_result(k)
         fast[0](k, self.x_f_mpc)
@@ -308,27 +408,28 @@ class Controller_batch:
 
 class Controller_groups(Controller_batch):
     """`Controller_batch(batch, ..., groups=G)`: the fleet as G independent stream groups, each a single-handle
-    Controller_batch of batch / G robots on its own stream (qrw_hip.StreamGroups' stream pool).
+    Controller_batch of batch / G robots on its own stream (qrw_hip.StreamGroups' stream pool).  Opt-in.
 
     Why: one handle steps the whole fleet with one launch per kernel, and the MPC launch ends with its longest solve while
     most of the chip is already idle; with two groups in flight one group's stragglers run beside the
-    other group's work.  The robots are independent, so every robot's results are those of the single handle, bit for bit
-    (tests/test_gpu_controller.py).
+    other group's work.  The robots are independent, so UNSTAGGERED every robot's results are those of the single handle,
+    bit for bit; STAGGERED (stagger=True) every robot of group g gets the results of a single handle started lag_of(g) fleet
+    ticks later, bit for bit, and holds q_init until then (tests/test_gpu_controller.py) -- the fleet's robots are then NOT
+    at the same iteration on a given tick, and self.k follows group 0.
 
     compute() keeps the single-handle contract: whole-fleet inputs in, whole-fleet Result out, valid on the caller's stream
-    (which is made to wait for every group: one join per iteration; measured slower than the single handle in the 1:10 loop,
-    see Controller_batch.__init__).  A caller whose own feedback is per robot as well can
+    (which is made to wait for every group: one join per iteration; measured slower than the single handle in the 1:10 loop
+    unless staggered, see Controller_batch.__init__).  A caller whose own feedback is per robot as well can
     skip the join and let the groups run free: `compute_group(g, ...)` with that group's slices `slice_of(g)` on the stream
     `stream_of(g)` (what bench.py's 1:10 figure does)."""
 
     def __init__(self, batch, q_init, dt_wbc=0.002, dt_mpc=0.02, k_mpc=10, T_gait=0.32, T_mpc=0.32, N_gait=20,
                  h_ref=0.2229, device=0, multiprocessing=False, loop_cus=None, mpc_lag=None, fused=True, groups=None,
-                 stagger=None, _out_views=None):
+                 stagger=None, deadline=None, _out_views=None):
         import torch
 
         G = auto_groups(batch, groups, multiprocessing)
-        if stagger is None:
-            stagger = groups is None  # groups chosen from the fleet size come staggered (see Controller_batch.__init__)
+        stagger = bool(stagger)  # opt-in: it changes what the robots of the late groups do (see Controller_batch.__init__)
         if G < 2 or int(batch) % G:
             raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (batch, G))
         self._torch = torch
@@ -344,6 +445,8 @@ class Controller_groups(Controller_batch):
         # for group 0 to have reached the same tick, which is what takes the two groups' solves apart.
         self.stagger = bool(stagger)
         self._delay = [(g * int(k_mpc)) // G if self.stagger else 0 for g in range(G)]
+        self.lag = tuple(self._delay)  # fleet ticks group g runs behind group 0 (and holds q_init for at the start)
+        self._init_deadline(deadline)
         self._calls = [0] * G
         self._views = None
         self._tick_ev = {}
@@ -378,6 +481,11 @@ class Controller_groups(Controller_batch):
 
     def slice_of(self, g):
         return self._sl[g]
+
+    def lag_of(self, g):
+        """Fleet ticks the robots of group g run behind group 0 (0 unless staggered): at fleet tick t they return their own
+        iteration t - lag_of(g), and hold q_init during the first lag_of(g) ticks."""
+        return self._delay[g]
 
     def group_started(self, g):
         """False while a staggered group has not run its first iteration yet (its slice of the result still holds q_init)."""
@@ -422,12 +530,12 @@ class Controller_groups(Controller_batch):
         """Will group g's next compute_group call carry an MPC solve (its robots' own clock at a multiple of k_mpc)?"""
         return self._calls[g] >= self._delay[g] and (self.groups[g].k % self.k_mpc) == 0
 
-    def compute(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
-        """One fleet tick: whole-fleet inputs in, whole-fleet Result out, valid on the caller's stream.  A group whose iteration
-        does not solve runs on the caller's stream itself (nothing to overlap: two launches of ~25 us); a group whose iteration
-        carries its MPC solve runs on the group's stream, forked from and joined to the caller's stream -- with staggered groups
-        (the default from 2048 robots on) that is one group on two ticks out of k_mpc, and the fleet's worst tick takes a
-        half-fleet solve instead of the whole fleet's."""
+    def _compute_any(self, joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code=0):
+        """compute(): one fleet tick, whole-fleet inputs in, whole-fleet Result out, valid on the caller's stream.  A group whose
+        iteration does not solve runs on the caller's stream itself (nothing to overlap: two launches of ~25 us); a group whose
+        iteration carries its MPC solve runs on the group's stream, forked from and joined to the caller's stream -- with
+        staggered groups that is one group on two ticks out of k_mpc, and the fleet's worst tick takes a half-fleet solve instead
+        of the whole fleet's."""
         torch = self._torch
         caller = torch.cuda.current_stream(self.dev)
         views = self._group_views((joy_v_ref, q_filt, v_filt, rpy, v_secu, joystick_code))

@@ -165,18 +165,24 @@ class MPC_Wrapper_batch:
     iteration for every instance on the caller's stream; get_latest_result_batch() -> (B,24,N).
     Before the first solve it returns the reference's default result (scripts/MPC_Wrapper.py:64-71).
 
-    groups (None = chosen from the fleet size: one handle below 2048 robots, two stream groups from there; 1 = one handle):
-    the fleet as independent stream groups, each with its own handle and stream (qrw_hip.StreamGroups' stream pool): a launch
-    ends with its longest solve while most of the chip is idle, and with two groups in flight one group's stragglers run
-    beside the other group's next solve (+10 % control steps/s at batch 4096).  Same results, bit for bit.  solve_batch
-    then returns at once; get_latest_result_batch() makes the caller's stream wait for the groups."""
+    groups (default 1: one handle, everything stream-ordered on the caller's stream; G > 1 opt-in): the fleet as independent
+    stream groups, each with its own handle and stream (qrw_hip.StreamGroups' stream pool): a launch ends with its longest
+    solve while most of the chip is idle, and with two groups in flight one group's stragglers run beside the other group's
+    next solve (+10 % control steps/s at batch 4096).  Same results, bit for bit.  solve_batch then returns with the solves in
+    flight on the groups' streams; get_latest_result_batch() makes the caller's stream wait for them.
 
-    def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0, groups=None):
+    Input lifetime (both forms): xref / fsteps (and a tensor k) may be refilled in place or dropped as soon as solve_batch
+    has returned -- with groups the call first copies them, on the caller's stream, into buffers the wrapper owns (two sets,
+    alternating, so that the copy of call n + 1 does not wait for the solves of call n; 14 MB at 4096 robots), and the groups'
+    streams read those.  (Rounds 4-5 read the caller's tensors from the groups' streams: a caller written for the
+    stream-ordered single handle raced with the running solve -- ADVICE r5.)"""
+
+    def __init__(self, dt, n_steps, T_gait, N_gait, batch, q_init=None, device=0, groups=1):
         import torch
 
         self._torch = torch
         self.B, self.n_steps, self.N_gait, self.device = int(batch), int(n_steps), int(N_gait), int(device)
-        G = int(groups) if groups is not None else (2 if (self.B >= 2048 and self.B % 2 == 0) else 1)
+        G = int(groups) if groups is not None else 1
         if G < 1 or self.B % G:
             raise qrw_hip.QrwError("batch %d does not split into %d equal groups" % (self.B, G))
         self.G, self.Bs = G, self.B // G
@@ -190,6 +196,11 @@ class MPC_Wrapper_batch:
                 if (device, g) not in qrw_hip.StreamGroups._streams:
                     qrw_hip.StreamGroups._streams[(device, g)] = torch.cuda.Stream(dev)
             self._streams = [qrw_hip.StreamGroups._streams[(device, g)] for g in range(G)]
+            mk = lambda dt_, *shape: torch.empty(shape, dtype=dt_, device=dev)
+            self._in = [(mk(torch.float64, self.B, 12, self.n_steps + 1), mk(torch.float64, self.B, self.N_gait, 12),
+                         mk(torch.int32, self.B)) for _ in range(2)]
+            self._in_done = [None, None]  # per input set: the events behind the groups' solves that read it
+            self._n_calls = 0
         first = np.zeros((self.B, 24, self.n_steps))
         if q_init is not None:
             q_init = np.asarray(q_init, dtype=np.float64).reshape(self.B, 19)
@@ -210,10 +221,26 @@ class MPC_Wrapper_batch:
         if self._out is None:
             self._out = torch.empty((self.B, 24, self.n_steps), dtype=torch.float64, device=xref.device)
         cur = torch.cuda.current_stream(self.device)
+        i = self._n_calls & 1
+        self._n_calls += 1
+        xs, fs, ks = self._in[i]
+        if self._in_done[i] is not None:  # the solves of two calls ago read this set: finished long ago in a loop, but say so
+            for ev in self._in_done[i]:
+                cur.wait_event(ev)
+        xs.copy_(xref)
+        fs.copy_(fsteps)
+        k_is_tensor = isinstance(k, torch.Tensor)
+        if k_is_tensor:
+            ks.copy_(k)
+        done = []
         for eng, st, sl in zip(self._bs, self._streams, self._sl):
-            st.wait_stream(cur)  # inputs produced on the caller's stream are ready (and the previous result has been consumed)
+            st.wait_stream(cur)  # the copies above are ready (and the previous result has been consumed)
             with torch.cuda.stream(st):
-                eng.mpc_solve(xref[sl], fsteps[sl], k[sl] if isinstance(k, torch.Tensor) else k, out=self._out[sl])
+                eng.mpc_solve(xs[sl], fs[sl], ks[sl] if k_is_tensor else k, out=self._out[sl])
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done.append(ev)
+        self._in_done[i] = done
         self._in_flight = True
         return 0
 

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -85,23 +86,28 @@ struct qrw_handle_s {
   qrw_iteration_buffers iter_bufs;  // qrw_iteration_bind
   bool iter_bound = false;
   hipStream_t host_stream = nullptr;
-  hipStream_t last_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool launched[4] = {false, false, false, false};
+  // (atomics: qrw_stream_destroy, called from whatever thread owns the stream, clears these in every live handle)
+  std::atomic<hipStream_t> last_stream[3] = {};
+  std::atomic<bool> launched[3] = {};
 };
 
 namespace {
 // state families of a handle: which launches a getter has to wait for
-enum Family { kFamMpc = 0, kFamWbc = 1, kFamPlan = 2, kFamCtrl = 3 };
+// (the controller-glue kernels write state no getter reads: their launches are not tracked)
+enum Family { kFamMpc = 0, kFamWbc = 1, kFamPlan = 2, kFamCount = 3 };
 inline void note_launch(qrw_handle_s* h, int fam, hipStream_t s) {
-  h->last_stream[fam] = s;
-  h->launched[fam] = true;
+  h->last_stream[fam].store(s, std::memory_order_relaxed);
+  h->launched[fam].store(true, std::memory_order_release);
 }
-// Wait for the family's most recent launch (whatever stream the caller gave it), nothing else on the device.  A stream the caller
-// has destroyed since (its work had to be complete for that) is answered with an error by the runtime: cleared, and the
-// conservative device-wide wait taken instead.
+// Wait for the family's most recent launch (whatever stream the caller gave it), nothing else on the device.  Only the LAST
+// stream of a family is remembered: a caller that launches one family of one handle on several streams that are not ordered
+// among themselves has to order them itself before it calls a getter.  A stream the caller has destroyed since (its work had to
+// be complete for that) is answered with an error by the runtime: cleared, and the conservative device-wide wait taken instead.
 hipError_t wait_family(qrw_handle_s* h, int fam) {
-  if (!h->launched[fam] || h->last_stream[fam] == h->host_stream) return hipSuccess;  // (host_stream work is waited for below / was at its call)
-  hipError_t e = hipStreamSynchronize(h->last_stream[fam]);
+  if (!h->launched[fam].load(std::memory_order_acquire)) return hipSuccess;
+  const hipStream_t last = h->last_stream[fam].load(std::memory_order_relaxed);
+  if (last == h->host_stream) return hipSuccess;  // (host_stream work is waited for below / was at its call)
+  hipError_t e = hipStreamSynchronize(last);
   if (e == hipSuccess) return e;
   (void)hipGetLastError();
   h->launched[fam] = false;
@@ -117,6 +123,19 @@ inline hipError_t h2d(qrw_handle_s* h, void* dst, const void* src, size_t bytes)
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->host_stream);
 }
 inline hipError_t host_done(qrw_handle_s* h) { return hipStreamSynchronize(h->host_stream); }
+// Every entry point that queues copies from / to the CALLER'S host buffers (or the handle's staging area) on host_stream holds one
+// of these: on ANY return -- the error paths too -- host_stream has drained, so nothing touches the caller's memory or h->stage
+// after the call has come back.  On the normal path the function's own host_done() has already waited; this second
+// wait on an idle stream costs ~1 us.
+struct HostStreamGuard {
+  qrw_handle_s* h;
+  explicit HostStreamGuard(qrw_handle_s* handle) : h(handle) {}
+  ~HostStreamGuard() {
+    if (h && h->host_stream) (void)hipStreamSynchronize(h->host_stream);
+  }
+  HostStreamGuard(const HostStreamGuard&) = delete;
+  HostStreamGuard& operator=(const HostStreamGuard&) = delete;
+};
 }  // namespace
 
 extern "C" const char* qrw_last_error(void) { return g_err.c_str(); }
@@ -532,6 +551,7 @@ extern "C" int qrw_mpc_solve_host(qrw_handle h, const double* h_xref, const doub
                                   int32_t num_iter_scalar, double* h_out) {
   if (!h || !h_xref || !h_fsteps || !h_out) return fail(-1, "qrw_mpc_solve_host: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   double* dx = h->stage;
   double* df = dx + B * 12 * (N + 1);
@@ -610,6 +630,7 @@ extern "C" int qrw_mpc_solve_sequence(qrw_handle h, int32_t K, const double* d_x
 extern "C" int qrw_mpc_sequence_error(qrw_handle h, int32_t* timed_out) {
   if (!h || !timed_out) return fail(-1, "qrw_mpc_sequence_error: null argument");
   DeviceScope dev_scope__(h->cfg.device);
+  HostStreamGuard host_guard__(h);
   *timed_out = 0;
   if (!h->seq_ctr) return 0;
   // like every other getter: waits for this handle's last MPC launch (the sequence in flight), not for the device
@@ -637,6 +658,7 @@ extern "C" int qrw_mpc_copy_iters(qrw_handle h, int32_t* d_iters, void* stream) 
 extern "C" int qrw_mpc_get_gait(qrw_handle h, int32_t b, double* h_gait, double* h_Sgait) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_gait: bad argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const int N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   HIP_OK(wait_family(h, kFamMpc), "sync");
   if (h_gait) {
@@ -661,6 +683,7 @@ extern "C" int qrw_mpc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
                                  double* h_dua_res) {
   if (!h) return fail(-1, "qrw_mpc_get_stats: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   HIP_OK(wait_family(h, kFamMpc), "sync");  // this handle's last solve only: another handle's launch in flight is not waited for
   if (h->pre_ctr) {  // a time-sliced launch whose queue gave up (never expected) left solves unfinished: say so, loudly
@@ -684,6 +707,7 @@ extern "C" int qrw_mpc_get_slice_stats(qrw_handle h, int32_t* levels, int32_t* c
                                        uint32_t* h_takers, uint32_t* h_finished) {
   if (!h || !levels || !chunk || !h_parks_per_level || !h_takers || !h_finished) return fail(-1, "qrw_mpc_get_slice_stats: null argument");
   DeviceScope dev_scope__(h->cfg.device);
+  HostStreamGuard host_guard__(h);
   *levels = h->pre_ctr ? h->pre_levels : 0;
   *chunk = h->pre_ctr ? h->pre_chunk : 0;
   for (int l = 0; l < qrw::kPreMaxLevels; l++) h_parks_per_level[l] = 0;
@@ -769,6 +793,7 @@ extern "C" int qrw_test_known_answer(int32_t N, int32_t mode, uint64_t lds_patte
 extern "C" int qrw_mpc_get_order(qrw_handle h, int32_t* h_order, float* h_ema, int32_t* has_order) {
   if (!h || !has_order) return fail(-1, "qrw_mpc_get_order: null argument");
   DeviceScope dev_scope__(h->cfg.device);
+  HostStreamGuard host_guard__(h);
   HIP_OK(wait_family(h, kFamMpc), "qrw_mpc_get_order sync");
   *has_order = h->mpc_have_order ? 1 : 0;
   const size_t B = h->cfg.batch;
@@ -782,6 +807,7 @@ extern "C" int qrw_mpc_get_state(qrw_handle h, int32_t b, double* h_x, double* h
                                  double* h_E, double* h_c) {
   if (!h || b < 0 || b >= h->cfg.batch) return fail(-1, "qrw_mpc_get_state: bad argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const int N = h->cfg.n_steps;
   const int T = qrw::mpc_threads(N);
   std::vector<double> s((size_t)qrw::kMpcStItems * T);
@@ -868,7 +894,6 @@ extern "C" int qrw_wbc_compute_result(qrw_handle h, const double* d_q, const dou
   if (qrw::wbc_launch(a, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_wbc_compute_result: kernel launch failed", hipGetLastError());
   note_launch(h, kFamWbc, (hipStream_t)stream);
-  note_launch(h, kFamCtrl, (hipStream_t)stream);
   return 0;
 }
 
@@ -903,6 +928,7 @@ extern "C" int qrw_wbc_compute_host(qrw_handle h, const double* h_q, const doubl
                                     double* h_f_with_delta, double* h_ddq_res, double* h_feet) {
   if (!h) return fail(-1, "qrw_wbc_compute_host: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   HIP_OK(wait_family(h, kFamWbc), "qrw_wbc_compute_host: earlier WBC step of this handle");
   Stager s(h);
@@ -924,6 +950,7 @@ extern "C" int qrw_wbc_get_stats(qrw_handle h, int32_t* h_iters, int32_t* h_stat
                                  double* h_k_since_contact) {
   if (!h) return fail(-1, "qrw_wbc_get_stats: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   HIP_OK(wait_family(h, kFamWbc), "sync");
   if (h_iters) HIP_OK(d2h(h, h_iters, h->wbc_iters, B * sizeof(int)), "D2H iters");
@@ -946,6 +973,7 @@ extern "C" int qrw_fixed_feet_host(qrw_handle h, const double* h_q12, const doub
                                    double* h_wf, double* h_af, double* h_Jf) {
   if (!h || !h_q12 || !h_dq12) return fail(-1, "qrw_fixed_feet_host: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   Stager s(h);
   qrw::WbcArgs a;
@@ -968,6 +996,7 @@ extern "C" int qrw_invkin_host(qrw_handle h, const double* h_contacts, const dou
                                double* h_q_step) {
   if (!h) return fail(-1, "qrw_invkin_host: null handle");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   Stager s(h);
   qrw::WbcArgs a;
@@ -989,6 +1018,7 @@ extern "C" int qrw_qpwbc_host(qrw_handle h, const double* h_M, const double* h_J
                               const double* h_RNEA, double* h_f_res, double* h_ddq_res, double* h_H) {
   if (!h || !h_M || !h_Jc || !h_f_cmd || !h_RNEA) return fail(-1, "qrw_qpwbc_host: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch;
   HIP_OK(wait_family(h, kFamWbc), "qrw_qpwbc_host: earlier WBC step of this handle");
   Stager s(h);
@@ -1054,6 +1084,7 @@ extern "C" int qrw_selftest_sweeps(double* max_err) {
 extern "C" int qrw_mpc_get_phase_cycles(qrw_handle h, double* h_prof /* [B][10] */) {
   if (!h || !h_prof) return fail(-1, "qrw_mpc_get_phase_cycles: null argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   HIP_OK(wait_family(h, kFamMpc), "sync");
   HIP_OK(d2h(h, h_prof, h->mpc_prof, (size_t)h->cfg.batch * qrw::kMpcProfItems * sizeof(double)), "D2H prof");
   HIP_OK(host_done(h), "D2H prof");
@@ -1119,6 +1150,7 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
                                      double* h_gait, double* h_target, double* h_feet_pva) {
   if (!h || !h->plan_ready) return fail(-1, "qrw_planner_call_host: planner not initialised");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const size_t B = h->cfg.batch, N = h->cfg.n_steps, Ng = h->cfg.N_gait;
   HIP_OK(wait_family(h, kFamPlan), "qrw_planner_call_host: earlier planner step of this handle");
   Stager s(h);
@@ -1148,6 +1180,7 @@ extern "C" int qrw_planner_call_host(qrw_handle h, int32_t mode, int32_t k, int3
 extern "C" int qrw_planner_get_host(qrw_handle h, int32_t which, int32_t b, int32_t count, double* h_out) {
   if (!h || !h_out || b < 0 || b >= h->cfg.batch || count < 1) return fail(-1, "qrw_planner_get_host: bad argument");
   DeviceScope dev_scope__(h->cfg.device);  // launches and copies go to the handle's GPU, the caller's current device is restored
+  HostStreamGuard host_guard__(h);
   const int off = qrw::planner_item_offset(h->cfg.N_gait, which);
   const size_t B = h->cfg.batch;
   HIP_OK(wait_family(h, kFamPlan), "sync");
@@ -1272,8 +1305,9 @@ extern "C" int qrw_stream_destroy(void* stream) {
   {
     std::lock_guard<std::mutex> lock(g_handles_mutex);
     for (qrw_handle_s* h : g_handles)
-      for (int f = 0; f < 4; f++)
-        if (h->launched[f] && h->last_stream[f] == (hipStream_t)stream) h->launched[f] = false;
+      for (int f = 0; f < kFamCount; f++)
+        if (h->launched[f].load(std::memory_order_acquire) && h->last_stream[f].load(std::memory_order_relaxed) == (hipStream_t)stream)
+          h->launched[f].store(false, std::memory_order_release);
   }
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   return e == hipSuccess ? 0 : fail(-10, "qrw_stream_destroy: hipStreamDestroy failed", e);
@@ -1324,7 +1358,6 @@ extern "C" int qrw_control_pre(qrw_handle h, int32_t k, const double* d_joy_vref
   if (qrw::control_pre_launch(cu, p, cw, d_x_f_mpc ? 1 : 0, (hipStream_t)stream) != 0)
     return fail(-11, "qrw_control_pre: launch failed", hipGetLastError());
   note_launch(h, kFamPlan, (hipStream_t)stream);
-  note_launch(h, kFamCtrl, (hipStream_t)stream);
   return 0;
 }
 

@@ -586,16 +586,23 @@ class Batch:
                             ("ddq_res", (B, 6)), ("feet", (B, 3, 3, 4)), ("result", (B, 5, 12))):
             setattr(b, "d_" + name, d(post[name], shape))
         b.d_error_flag = ef.data_ptr()
-        _check(self._lib.qrw_iteration_bind(self._handle, C.byref(b)), "qrw_iteration_bind")
-        keep = (pre, post, inputs)  # the buffers stay alive as long as the callable does
+        f_bind = self._lib.qrw_iteration_bind
+        _check(f_bind(self._handle, C.byref(b)), "qrw_iteration_bind")
+        # the library keeps ONE binding per handle (binding again replaces it): every callable remembers which binding is its
+        # own and puts it back before it steps if another bind_iteration of this handle came in between (an earlier
+        # callable must not run on the buffers of a later bind)
+        self._bind_gen = gen = getattr(self, "_bind_gen", 0) + 1
+        keep = (pre, post, inputs, b)  # the buffers stay alive as long as the callable does
         f_step, h, cur_stream = self._lib.qrw_iteration_step, self._handle, self._stream
         fixed = None if stream is None else _vp(stream.cuda_stream)
-        last = [None, None]  # the MPC result tensor validated last, and its pointer (the loop alternates between a few buffers)
+        last = [None, None, 0]  # the MPC result tensor validated last, its pointer argument and address (the loop alternates between a few buffers)
 
         def step(k, x_f_mpc):
-            _ = keep
-            if x_f_mpc is not last[0]:
-                last[0], last[1] = x_f_mpc, d(x_f_mpc, (B, 24, N))
+            if self._bind_gen != gen:
+                _check(f_bind(h, C.byref(keep[3])), "qrw_iteration_bind")
+                self._bind_gen = gen
+            if x_f_mpc is not last[0] or x_f_mpc.data_ptr() != last[2]:  # (same object, other storage: t.data = ..., set_())
+                last[0], last[1], last[2] = x_f_mpc, d(x_f_mpc, (B, 24, N)), x_f_mpc.data_ptr()
             rc = f_step(h, k, last[1], cur_stream() if fixed is None else fixed)
             if rc:
                 _check(rc, "qrw_iteration_step")

@@ -25,9 +25,9 @@ def new_vref(scale):
 
 
 with torch.cuda.stream(torch.cuda.Stream(dev)):
-    # QRW_LOOP_GROUPS=auto: the object Controller_batch builds by itself at this fleet size (two staggered stream groups)
+    # QRW_LOOP_GROUPS=auto: two staggered stream groups (what Controller_batch built by itself from 2048 robots on in rounds 4-5)
     grp = os.environ.get("QRW_LOOP_GROUPS", "1")
-    ctl = Controller_batch(B, q_init, groups=(None if grp == "auto" else int(grp)), multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N,
+    ctl = Controller_batch(B, q_init, groups=(2 if grp == "auto" else int(grp)), stagger=(grp == "auto"), multiprocessing=mp, T_gait=0.02 * N, T_mpc=0.02 * N,
                            N_gait=max(20, N + 4))
     vref = new_vref(0.5)
     qf = torch.zeros((B, 19), dtype=torch.float64, device=dev); qf[:, 2], qf[:, 6] = 0.2229, 1.0

@@ -457,15 +457,16 @@ def test_stream_groups_controller_equals_the_single_handle(mode):
         Controller_batch(7, Q_INIT, groups=2)
 
 
-@pytest.mark.parametrize("free,defaults", [(False, False), (True, False), (False, True)], ids=["joined", "free", "default_object"])
+@pytest.mark.parametrize("free,defaults", [(False, False), (True, False), (False, True)], ids=["joined", "free", "for_deadline"])
 def test_staggered_stream_groups_equal_single_handles_started_late(free, defaults):
     """Controller_batch(..., groups=2, stagger=True): group 1 starts k_mpc / 2 fleet ticks late, so the two groups' MPC solves fall
     on different ticks (the reference solves on k % k_mpc == 0 of the robot's own clock, scripts/Controller.py:246-253).  Every
     robot must see exactly a single-handle controller started that many ticks later: Result and error flag of group g at fleet
-    tick t equal, bit for bit, those of a single handle over the group's robots at its tick t - delay; before its start a
+    tick t equal, bit for bit, those of a single handle over the group's robots at its tick t - lag_of(g); before its start a
     group's robots are commanded to hold q_init (P 3, D 0.2, zero v_des / tau_ff).  Joined (compute) and never joined
-    (compute_group on the groups' streams).  default_object: a fleet of 2048 robots built WITHOUT groups / stagger arguments is
-    exactly that object (auto_groups), a fleet below that size a single handle."""
+    (compute_group on the groups' streams).  for_deadline: what Controller_batch.for_deadline builds for 2048 robots and the
+    reference's 2 ms slot is exactly that object; WITHOUT arguments a fleet of any size is one handle (the
+    staggered form changes what half the robots do, so it is never chosen silently)."""
     import torch
     from Controller import Controller_batch, Controller_groups
 
@@ -483,15 +484,19 @@ def test_staggered_stream_groups_equal_single_handles_started_late(free, default
         return qf, vf, torch.zeros((n, 3), dtype=torch.float64, device="cuda"), torch.zeros((n, 12), dtype=torch.float64, device="cuda")
 
     if defaults:
-        ctl = Controller_batch(B, qi)
-        assert not isinstance(Controller_batch(2046, Q_INIT), Controller_groups)        # below the threshold: one handle
-        assert not isinstance(Controller_batch(B, Q_INIT, groups=1), Controller_groups)  # groups=1 stays available
+        ctl = Controller_batch.for_deadline(B, qi)
+        assert ctl.deadline == 0.002
+        for n in (2046, 2048, 4096):
+            assert not isinstance(Controller_batch(n, Q_INIT), Controller_groups)       # no arguments: one handle at every size
         assert not Controller_batch(B, Q_INIT, groups=2).stagger                         # explicit groups: not staggered unless asked
-        mp = Controller_batch(B, Q_INIT, multiprocessing=True)                          # the asynchronous mode: always one handle
-        assert not isinstance(mp, Controller_groups)
+        small = Controller_batch.for_deadline(512, Q_INIT)                               # fits the slot synchronously
+        assert not isinstance(small, Controller_groups) and not small.multiprocessing
+        mp = Controller_batch.for_deadline(4096, Q_INIT)                                 # only the asynchronous mode fits
+        assert not isinstance(mp, Controller_groups) and mp.multiprocessing
         mp.stop_parallel_loop()
     else:
         ctl = Controller_batch(B, qi, groups=2, stagger=True, k_mpc=k_mpc)
+    assert ctl.lag == (0, k_mpc // 2) and ctl.lag_of(1) == k_mpc // 2
     assert isinstance(ctl, Controller_groups) and ctl.G == 2 and ctl.stagger and ctl._delay == [0, k_mpc // 2]
     qf, vf, rpy, vs = state(B, qi)
     vf[:, :6] = vref
@@ -634,3 +639,60 @@ def test_closed_loop_does_not_depend_on_uninitialised_buffers(oracle_mod, monkey
 
     monkeypatch.setattr(torch, "empty", poisoned_empty)
     _closed_loop(oracle_mod, mode, True, DEFAULT_CFG, 45)
+
+
+def test_deadline_monitor_reports_the_overrun_and_for_deadline_avoids_it():
+    """VERDICT r5 item 5: the reference runs its loop in a slot of dt_wbc = 2 ms (/root/reference/src/config_solo12.yaml:6;
+    scripts/Controller.py:246-253: every k_mpc-th iteration carries the MPC solve).  The default object (one handle, synchronous)
+    at 4096 robots cannot keep that: with deadline=dt_wbc it must say so -- once, as a RuntimeWarning that names the mode to use,
+    and in ctl.overrun --; the object Controller_batch.for_deadline builds for the same fleet (asynchronous MPC) paced at 2 ms
+    must not overrun."""
+    import time
+    import warnings
+
+    import torch
+    from Controller import Controller_batch, recommended_mode
+
+    B = 4096
+    rng = np.random.default_rng(5)
+    vref = _t(rng.uniform(-0.3, 0.3, (B, 6)) * np.array([1.0, 0.5, 0, 0, 0, 1.0]))
+
+    def loop(ctl, iters, paced):
+        qf = torch.zeros((B, 19), dtype=torch.float64, device="cuda")
+        qf[:, 2], qf[:, 6] = 0.2229, 1.0
+        qf[:, 7:] = _t(np.broadcast_to(Q_INIT, (B, 12)).copy())
+        vf = torch.zeros((B, 18), dtype=torch.float64, device="cuda")
+        vf[:, :6] = vref
+        rpy = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        vs = torch.zeros((B, 12), dtype=torch.float64, device="cuda")
+        nxt = time.perf_counter()
+        for _ in range(iters):
+            r = ctl.compute(vref, qf, vf, rpy, vs)
+            qf[:, 7:].copy_(r.q_des)
+            vf[:, 6:].copy_(r.v_des)
+            if paced:
+                torch.cuda.current_stream().synchronize()
+                nxt += 0.002
+                while time.perf_counter() < nxt:
+                    pass
+        return ctl.deadline_flush()
+
+    with torch.cuda.stream(torch.cuda.Stream()):
+        ctl = Controller_batch(B, Q_INIT, deadline=0.002)
+        assert ctl.deadline == 0.002 and ctl.overrun is None and not ctl.multiprocessing
+        with pytest.warns(RuntimeWarning, match=r"deadline 2\.00 ms.*multiprocessing=True") as rec:
+            worst = loop(ctl, 51, paced=False)
+        assert len([w for w in rec if issubclass(w.category, RuntimeWarning)]) == 1  # said once
+        assert ctl.overrun is not None and ctl.overrun[0] == worst > 0.002 and ctl.overrun[1] % ctl.k_mpc == 0
+        assert recommended_mode(B, 0.002) == dict(multiprocessing=True)
+        ok = Controller_batch.for_deadline(B, Q_INIT)
+        assert ok.multiprocessing and ok.deadline == 0.002
+        with torch.cuda.stream(ok.loop_stream):
+            loop(ok, 30, paced=True)  # start-up: the first two solves set the QP up and start cold
+            ok.worst_iteration, ok.overrun = 0.0, None
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                worst_ok = loop(ok, 60, paced=True)
+        print("4096 robots, 2 ms slot: synchronous worst iteration %.2f ms (reported), asynchronous worst %.2f ms" % (worst * 1e3, worst_ok * 1e3))
+        assert ok.overrun is None and 0.0 < worst_ok < 0.002
+        ok.stop_parallel_loop()

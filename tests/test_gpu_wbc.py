@@ -341,9 +341,10 @@ def test_stream_groups_give_the_single_handle_results(synth_mod):
 
 
 def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
-    """MPC_Wrapper_batch WITHOUT a groups argument on a fleet of 2052 robots (two handles on two streams: the default from 2048
-    robots on) returns what the single handle (groups=1) returns, bit for bit, for int and per-instance iteration arguments,
-    incl. the default result before the first solve."""
+    """MPC_Wrapper_batch(groups=2) on a fleet of 2052 robots (two handles on two streams, opt-in; without the argument: one handle
+    at every fleet size) returns what the single handle returns, bit for bit, for int and per-instance iteration arguments,
+    incl. the default result before the first solve -- and the caller may REFILL ITS INPUT TENSORS IN PLACE as soon as
+    solve_batch has returned (the groups' streams read copies the wrapper owns, not the caller's tensors)."""
     import torch
 
     import MPC_Wrapper
@@ -351,16 +352,26 @@ def test_wrapper_batch_stream_groups_equal_the_single_handle(synth_mod):
     B, N, K = 2052, 16, 4
     sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=99200)
     a = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=1)
-    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B)
+    b = MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, B, groups=2)
     assert a.G == 1 and b.G == 2 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 8).G == 1
-    assert MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 2046).G == 1 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 64, groups=2).G == 2
+    assert MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 4096).G == 1 and MPC_Wrapper.MPC_Wrapper_batch(0.02, N, 0.32, 20, 64, groups=2).G == 2
+    xb, fb = (torch.empty((B,) + shp, dtype=torch.float64, device="cuda") for shp in ((12, N + 1), (20, 12)))
+    kb = torch.empty((B,), dtype=torch.int32, device="cuda")
     assert torch.equal(a.get_latest_result_batch(), b.get_latest_result_batch())  # the default forces
     for s in range(K):
         d = sb.step(s)
         x, f = torch.from_numpy(d["xref"]).cuda(), torch.from_numpy(d["fsteps"]).cuda()
         k = s if s % 2 == 0 else torch.full((B,), s, dtype=torch.int32, device="cuda")
         a.solve_batch(k, x, f)
-        b.solve_batch(k, x, f)
+        # the grouped wrapper gets buffers that are overwritten with garbage right behind the call, on the caller's stream
+        xb.copy_(x)
+        fb.copy_(f)
+        if isinstance(k, torch.Tensor):
+            kb.copy_(k)
+        b.solve_batch(kb if isinstance(k, torch.Tensor) else k, xb, fb)
+        xb.fill_(float("nan"))
+        fb.fill_(1e9)
+        kb.fill_(-7)
         assert torch.equal(a.get_latest_result_batch(), b.get_latest_result_batch()), s
         torch.cuda.synchronize()
     sa, sb_ = a.stats(), b.stats()

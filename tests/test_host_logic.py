@@ -143,14 +143,25 @@ def test_priority_levels_of_the_time_sliced_launch_beat_one_fifo_on_the_recorded
 
 
 def test_default_groups_of_the_fleet_objects():
-    """Host logic of the default objects (no GPU): one handle below 2048 robots, two stream groups from there, one handle for odd
-    fleets and in the asynchronous mode; Controller_batch.__new__ reads `multiprocessing` from the position it has in __init__."""
+    """Host logic of the fleet objects (no GPU): ONE handle by default at every fleet size (stream groups and staggering are opt-in:
+    ADVICE r5), recommended_mode() = the realtime_slot table (sync up to 1024 robots, two staggered groups up to 2048, asynchronous
+    up to 4096 at the reference's 2 ms slot, scaled with the deadline); Controller_batch.__new__ reads `multiprocessing` from the
+    position it has in __init__."""
     import inspect
 
-    from Controller import AUTO_GROUPS_MIN_BATCH, Controller_batch, auto_groups
+    from Controller import REALTIME_SLOT_FITS, Controller_batch, auto_groups, recommended_mode
 
-    assert AUTO_GROUPS_MIN_BATCH == 2048
-    assert [auto_groups(b) for b in (1, 64, 2046, 2047, 2048, 2049, 4096, 32768)] == [1, 1, 1, 1, 2, 1, 2, 2]
+    assert [auto_groups(b) for b in (1, 64, 2046, 2048, 4096, 32768)] == [1] * 6
     assert auto_groups(4096, multiprocessing=True) == 1 and auto_groups(4096, 4, True) == 4 and auto_groups(64, 2) == 2
+    assert dict(REALTIME_SLOT_FITS) == {"sync": 1024, "staggered_groups": 2048, "async": 4096}
+    assert recommended_mode(1) == {} and recommended_mode(1024) == {}
+    assert recommended_mode(1026) == dict(groups=2, stagger=True) == recommended_mode(2048)
+    assert recommended_mode(1025) == dict(multiprocessing=True)  # an odd fleet does not split
+    assert recommended_mode(2050) == dict(multiprocessing=True) == recommended_mode(4096)
+    assert recommended_mode(4098) is None and recommended_mode(4096, 0.001) is None
+    assert recommended_mode(2048, 0.004) == {} and recommended_mode(8192, 0.004) == dict(multiprocessing=True)
     names = list(inspect.signature(Controller_batch.__init__).parameters)
     assert names[:2] == ["self", "batch"] and names.index("multiprocessing") - 2 == 9  # args[9] in __new__
+    import MPC_Wrapper
+
+    assert inspect.signature(MPC_Wrapper.MPC_Wrapper_batch.__init__).parameters["groups"].default == 1
