@@ -58,6 +58,35 @@ F_WBC = 15.0e3       # kinematics + 2x RNEA + InvKin + QP build
 F_WBC_IT = 1.0e3     # per 12-variable ADMM iteration
 
 
+def roofline_block(B, N, N_gait, launch_ms, iters, gaits=None, kernel=None, wbc_too=True):
+    """The `roofline` object of one bench leg: the MPC kernel's algorithmic flops per launch -- ADMM iteration
+    counts of EVERY timed launch x f_iter(N), plus one factorisation and assembly per instance -- over the launch durations
+    measured with HIP events on the launch stream, against the FP64 peak; HBM traffic per launch from the committed rocprofv3
+    --pmc passes of the same shape (null where that shape has not been profiled on these kernel sources).
+    launch_ms: (K,) durations, iters: (K, B) iteration counts."""
+    launch_ms = np.asarray(launch_ms, dtype=np.float64)
+    iters = np.asarray(iters, dtype=np.float64).reshape(len(launch_ms), -1)
+    K = len(launch_ms)
+    flops = iters.sum(axis=1) * f_iter(N) + B * (f_fac(N) + F_ASM)   # per launch
+    achieved = float(flops.sum() / (launch_ms.sum() * 1e-3))
+    bytes_launch = B * b_alg(N, N_gait)
+    traffic, traffic_src = pmc_traffic_bytes(B, N, gaits)
+    if kernel is None:
+        kernel = "mpc_solve_kernel<%d,%s,false,%s>" % (1 if N <= 16 else 2, "true" if N in (16, 32) else "false",
+                                                       "true" if (N > 16 and B > 512) else "false")
+    return {
+        "kernel": kernel, "bound": "fp64-valu-issue", "achieved": achieved / 1e12, "peak": PEAK_FP64 / 1e12,
+        "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": traffic, "traffic_source": traffic_src,
+        "launch_ms_mean": float(launch_ms.mean()), "launch_ms_min": float(launch_ms.min()), "launch_ms_max": float(launch_ms.max()),
+        "launches": int(K), "mean_admm_iters": float(iters.mean()), "max_admm_iters": int(iters.max()),
+        "flops_per_iteration": f_iter(N), "flops_per_factorisation": f_fac(N),
+        "algorithmic_bytes_per_launch": bytes_launch,
+        "hbm_frac_algorithmic": (bytes_launch / (launch_ms.mean() * 1e-3)) / PEAK_HBM,
+        "note": "roof = FP64 peak of gfx950 (vector = matrix = 78.6 TFLOP/s); neither of the contract's two labels fits: the "
+                "kernel is bound by FP64 VALU instruction issue on dependent chains (one wavefront per SIMD, no MFMA issued, "
+                "HBM at a fraction of a per cent), DESIGN.md 4.1"}
+
+
 def b_alg(N, N_gait):
     """compulsory HBM bytes per control step: inputs + outputs + persisted solver state read and written once."""
     io = 8 * (12 * (N + 1) + 12 * N_gait + 89 + 24 * N + 48)
@@ -322,21 +351,7 @@ def main():
         wbc_ms = np.array([a.elapsed_time(b) for a, b in ev_w[:K]])
         iters = it_dev[:K].cpu().numpy().astype(np.float64)          # (K, B)
         ms, ws = eng.mpc_stats(), eng.wbc_stats()
-        flops = iters.sum(axis=1) * f_iter(N) + B * (f_fac(N) + F_ASM)   # per launch
-        achieved = float(flops.sum() / (mpc_ms.sum() * 1e-3))
-        bytes_launch = B * b_alg(N, N_gait)
-        traffic, traffic_src = pmc_traffic_bytes(B, N)
-        out["roofline"] = {
-            "kernel": "mpc_solve_kernel", "bound": "fp64-valu-issue", "achieved": achieved / 1e12, "peak": PEAK_FP64 / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP64, "traffic": traffic, "traffic_source": traffic_src,
-            "launch_ms_mean": float(mpc_ms.mean()), "launch_ms_min": float(mpc_ms.min()), "launch_ms_max": float(mpc_ms.max()),
-            "launches": int(K), "mean_admm_iters": float(iters.mean()), "max_admm_iters": int(iters.max()),
-            "flops_per_iteration": f_iter(N), "flops_per_factorisation": f_fac(N),
-            "algorithmic_bytes_per_launch": bytes_launch,
-            "hbm_frac_algorithmic": (bytes_launch / (mpc_ms.mean() * 1e-3)) / PEAK_HBM,
-            "note": "roof = FP64 peak of gfx950 (vector = matrix = 78.6 TFLOP/s); neither of the contract's two labels fits: the "
-                    "kernel is bound by FP64 VALU instruction issue on dependent chains (one wavefront per SIMD, no MFMA issued, "
-                    "HBM at a fraction of a per cent), DESIGN.md 4.1"}
+        out["roofline"] = roofline_block(B, N, N_gait, mpc_ms, iters, gaits, kernel="mpc_solve_kernel")
         out["kernels_ms"] = {"mpc_solve_kernel": float(mpc_ms.mean()), "wbc_kernel": float(wbc_ms.mean())}
         out["solver"] = {"mpc_solved_last_step": int((ms["status"] == 1).sum()), "mpc_instances": B,
                          "wbc_mean_iters": float(ws["iters"].mean())}
@@ -477,6 +492,7 @@ def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0, a
                 "max_iter_exit_share": float((iters >= 4000).mean()),
                 "solved_share_last_step": float((status == 1).mean()),
                 "roofline_frac": float(flops / (ms.sum() * 1e-3) / PEAK_FP64), "flops_per_iteration": f_iter(N),
+                "roofline": roofline_block(B, N, N_gait, ms, iters, gaits if label.startswith("open-loop") else None),
                 "timed_steps": K, "warmup_steps": W, "sequence": label}
 
     sb = synth.SyntheticBatch(B, N, N_gait=N_gait, gaits=gaits, n_seq=W + K)
@@ -510,7 +526,7 @@ def config_leg(B, N, gaits, dev, W, K, mpc_only=False, closed=False, groups=0, a
         gen.close()
         c = timed(cseq, "closed receding-horizon sequence (SURVEY 8(d))")
         res["closed_loop"] = {k: c[k] for k in ("value", "unit", "ms_per_step", "launch_ms_mean", "mean_admm_iters", "max_admm_iters",
-                                                "max_iter_exit_share", "roofline_frac")}
+                                                "max_iter_exit_share", "roofline_frac", "roofline")}
     if acc:
         res["accuracy"] = leg_accuracy(acc[0], acc[1], N, N_gait, gaits, mpc_only, dev, threads)
     return res
@@ -638,18 +654,29 @@ def mpc_source_stamp():
     return h.hexdigest()
 
 
-def pmc_traffic_bytes(B, N):
+PMC_SHAPES = {  # (batch, horizon, gaits) of the bench legs that have committed counter passes -> tag of their summary files
+    (4096, 16, ("trot",)): "bench_b4096",                                 # the headline (BASELINE config 3)
+    (4096, 32, ("walk", "trot", "bounding")): "n32_mixed_time_sliced",    # config 4
+    (256, 16, ("trot",)): "bench_b256",                                   # config 2
+    (1, 16, ("trot",)): "bench_b1",                                       # the metric's batch-1 point
+}
+
+
+def pmc_traffic_bytes(B, N, gaits=None):
     """HBM bytes per mpc_solve_kernel launch.  NOT measured by this run: read from the committed rocprofv3 PMC passes of
-    this same command (profiles/, separate --pmc runs as MI355X_MICROARCH.md prescribes; FETCH_SIZE / WRITE_SIZE are in
-    KiB; the kernel's accesses are 8 bytes per lane, a width the guide marks uncalibrated on gfx950, so no correction
-    factor is applied).  Only valid for the profiled shape (batch 4096, N = 16) AND the profiled kernel: the summary carries
-    a stamp of the kernel's sources (scripts/pmc_profile.sh writes it), and a summary whose stamp differs from the sources
-    this run was built from is refused (traffic null) instead of silently going stale."""
-    if (B, N) != (4096, 16):
+    the same bench shape (profiles/<round>_pmc_summary_<tag>.json, separate --pmc runs as MI355X_MICROARCH.md prescribes:
+    scripts/pmc_profile.sh; FETCH_SIZE / WRITE_SIZE are in KiB; the kernel's accesses are 8 bytes per lane, a width the guide
+    marks uncalibrated on gfx950, so no correction factor is applied).  Only valid for a profiled shape (PMC_SHAPES: the open-loop
+    workload of that batch, horizon and gait mix) AND the profiled kernel: every summary carries a stamp of the kernel's sources,
+    and a summary whose stamp differs from the sources this run was built from is refused (traffic null) instead of silently
+    going stale."""
+    tag = PMC_SHAPES.get((int(B), int(N), tuple(gaits) if gaits is not None else None))
+    if tag is None:
         return None, None
     now = mpc_source_stamp()
     refused = []
-    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary_bench_b4096.json")), reverse=True):
+    suffix = "_pmc_summary_%s.json" % tag
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix)), reverse=True):
         path = os.path.join(ROOT, "profiles", name)
         try:
             rows = json.load(open(path))
@@ -665,7 +692,7 @@ def pmc_traffic_bytes(B, N):
             if "mpc_solve_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot += r["mean"] * 1024.0
         if tot:
-            return tot, "profiles/%s (static: rocprofv3 --pmc passes of this command on these kernel sources, not collected by this run)" % name
+            return tot, "profiles/%s (static: rocprofv3 --pmc passes of this shape on these kernel sources, not collected by this run)" % name
     return None, "refused: " + "; ".join(refused) if refused else None
 
 
@@ -983,6 +1010,24 @@ def realtime_slot_leg(sb_full, N, N_gait, dev, batches=(64, 256, 1024, 2048, 409
                     "the robots); batches tested: %s" % (list(batches),)}
 
 
+def physical_cores_allowed():
+    """Physical cores among the logical CPUs this process may run on ((physical id, core id) pairs of /proc/cpuinfo); the
+    number of allowed logical CPUs if /proc/cpuinfo does not say."""
+    allowed = os.sched_getaffinity(0)
+    cores, proc, phys = set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                proc = int(ln.split(":")[1])
+            elif ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id") and proc in allowed:
+                cores.add((phys, ln.split(":")[1].strip()))
+    except Exception:
+        pass
+    return len(cores) if cores else len(allowed)
+
+
 def host_cpu_info():
     """What the CPU baseline ran on: model name, logical CPUs of the box and of this process, clocks from /proc/cpuinfo."""
     info = {"model": None, "logical_cpus": os.cpu_count(), "cpus_allowed": ALLOWED_CPUS, "mhz_now_max": None,
@@ -1061,7 +1106,37 @@ def cpu_baseline(synth, Bc, N, N_gait, gaits, threads, steps):
                 t1 += time.perf_counter() - a
         t1s.append(t1)
     t1 = min(t1s)
-    return ({"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port",
+    # the same restatement on ALL the host cores this process may use (north_star: "the same box's host cores"): one thread per
+    # physical core, the sample grown in proportion so that the leg takes the same wall time as the 16-thread one
+    t_all = min(ALLOWED_CPUS, physical_cores_allowed())
+    if t_all > cores:
+        # (bounded: at most four times the 16-thread sample and ~25 s of wall time -- on a shared host the per-thread rate of 128
+        # threads is a fraction of that of 16, BENCH r6: the leg must not stretch the default bench run)
+        B_all = Bc * min(t_all // cores, 4)
+        sba = synth.SyntheticBatch(B_all, N, N_gait=N_gait, gaits=gaits, n_seq=steps + 1)
+        ma, wa = oracle.MPCBatch(B_all, 0.02, N, 0.02 * N, N_gait, fast=True), oracle.WbcBatch(B_all, 0.002, fast=True)
+        ta, done = 0.0, 0
+        for s in range(steps + 1):
+            d = sba.step(s)
+            a = time.perf_counter()
+            r = ma.run(s, d["xref"], d["fsteps"], t_all)
+            wa.compute(d["q"], d["dq"], np.ascontiguousarray(r[:, 12:, 0]), d["contacts"], d["pgoals"], d["vgoals"], d["agoals"], t_all)
+            if s > 0:
+                ta += time.perf_counter() - a
+                done += 1
+                if ta > 25.0 and done >= 3:
+                    break
+        all_cores = {"value": B_all * done / ta, "unit": "steps/s", "cores": t_all, "kind": "port",
+                     "loadavg_1min_after": (os.getloadavg()[0] if hasattr(os, "getloadavg") else None),
+                     "sample": "%d instances x %d control steps (after the set-up step) of the headline sequence, %.1f s of wall time; one "
+                               "OpenMP thread per physical core this process may use (%d logical CPUs allowed, not pinned, host shared "
+                               "with other jobs: see host_cpu.loadavg_1min); CPU restatement oracle/ (OSQP-0.6-style, not OSQP itself)"
+                               % (B_all, done, ta, ALLOWED_CPUS)}
+        del ma, wa, sba
+    else:
+        all_cores = {"value": None, "cores": t_all, "sample": "not run: this process may use %d logical CPUs / %d physical cores, no more "
+                                                             "than the %d threads of the figure above" % (ALLOWED_CPUS, t_all, cores)}
+    return ({"value": Bc * steps / tot, "unit": "steps/s", "cores": cores, "kind": "port", "all_cores": all_cores,
              "host_cpu": host_cpu_info(), "pinned": omp_pinned(),
              "single_instance_single_thread_steps_per_s": 32 / t1,
              "single_instance_single_thread_passes_steps_per_s": [32 / t for t in t1s],
