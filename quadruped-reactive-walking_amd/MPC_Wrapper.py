@@ -40,6 +40,19 @@ def quaternionToRPY(quat):
     return np.array([[angle(r32, r33)], [pitch], [angle(r21, r11)]])
 
 
+class _EventFlag:
+    """`.value` of the reference's multiprocessing.Value('b') flag `newResult`, answered from the solve's HIP event: True
+    from the moment the asynchronous solve has finished until get_latest_result() has taken its result."""
+
+    def __init__(self, wrapper):
+        self._w = wrapper
+
+    @property
+    def value(self):
+        ev = self._w._event
+        return bool(ev is not None and ev.query())
+
+
 class MPC_Wrapper:
     """Wrapper of the OSQP MPC (scripts/MPC_Wrapper.py:20-71).
 
@@ -76,6 +89,9 @@ class MPC_Wrapper:
             self._stream = torch.cuda.Stream()
             self._event = None
             self._pending = None
+            # scripts/MPC_Wrapper.py:50-52: the shared flag the child process raises when a result is ready and
+            # get_latest_result lowers when it takes it; callers poll `newResult.value` (scripts/test_mpc.py:65)
+            self.newResult = _EventFlag(self)
         else:
             # Create the new version of the MPC solver object (scripts/MPC_Wrapper.py:58-61)
             self.mpc = MPC.MPC(dt, n_steps, T_gait, self.N_gait)
