@@ -334,7 +334,7 @@ int qrw_stream_wait_stream(qrw_handle h, void *waiter, void *signaller);
  * four-stance immobile scenario, scripts/test_mpc.py:54-62: 350 ADMM iterations, equal vertical forces, see
  * csrc/qrw_api.hip).  0 = ok, 1 = sweep mismatch, 2 = the known-answer solve is wrong, <0 = HIP error. *max_err (of the
  * sweep check) may be NULL.  qrw_create runs the known-answer solve once per process and device and fails with -20 if
- * this build of the library computes wrong results. */
+ * this build of the library computes wrong results (docs/HISTORY.md 6b). */
 int qrw_selftest_sweeps(double *max_err);
 
 /* workspace sizes, for callers that budget HBM */

@@ -24,7 +24,7 @@
 namespace qrw {
 
 // -DQRW_PROFILE_PRE (diagnostic build, scripts/gpu_loop_only.py): clocks per phase of control_pre_kernel, summed over its
-// wavefronts and printed to stderr every 50th launch (the figures quoted in DESIGN.md 4.4)
+// wavefronts and printed to stderr every 50th launch (the figures quoted in DESIGN.md 4.3, docs/HISTORY.md 4.4)
 #ifdef QRW_PROFILE_PRE
 __device__ unsigned long long qrw_pre_prof[16];
 #define PP(k_) do { if (threadIdx.x == 0 && pp_last != 0) { const long long t__ = clock64(); atomicAdd(&qrw_pre_prof[k_], (unsigned long long)(t__ - pp_last)); pp_last = t__; } } while (0)
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64) void control_pre_kernel(ControllerArgs cu, Plan
 // foot's own lane, the shared scalar work (state update, gait matrices as bit masks, yaw sines) redundantly on all four, the
 // stores are dealt to the lanes, and the three pieces hand over through REGISTERS instead of through their HBM operands.
 // One thread per instance was 64 wavefronts of pure latency on 1024 SIMDs (57 % of the wave cycles parked at s_waitcnt,
-// DESIGN.md 4.4); per lane this does about a third of the instructions and a quarter of the dependent HBM round trips.
+// DESIGN.md 4.3, docs/HISTORY.md 4.4); per lane this does about a third of the instructions and a quarter of the dependent HBM round trips.
 // Arithmetic, expression by expression, is that of update_state / planner_body / wbc_inputs above (parity: the fused and
 // the separate control loops are both checked against the chained CPU oracles, tests/test_gpu_controller.py).
 namespace {

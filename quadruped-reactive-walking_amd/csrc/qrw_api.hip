@@ -219,7 +219,7 @@ static void debug_poison_lds(hipStream_t stream) {
 
 // Known-answer check of THIS build of mpc_solve_kernel, run by qrw_create once per process, device and INSTANTIATION the
 // handle will launch (and by qrw_selftest_sweeps for all of them).  Why it exists: the kernel lives at the edge of the register
-// file, and one combination of compiler options has produced a library in which every solve diverges; the parity
+// file, and one combination of compiler options (docs/HISTORY.md 6b) has produced a library in which every solve diverges; the parity
 // tests catch that, a deployment that only rebuilds the library would not -- and each of the ten instantiations is its own piece
 // of generated code (the N = 32 forms sit closest to the register limit).  Case: the reference's four-stance immobile scenario
 // (scripts/test_mpc.py:54-62: height 0.2447..., feet at (+-0.195, +-0.147)), first MPC call, at the handle's own horizon N.
@@ -339,7 +339,7 @@ static int kat_fail(const char* who, int N, int mode, const KatResult& r) {
   snprintf(msg, sizeof(msg),
            "%s: the known-answer self-test of mpc_solve_kernel failed on this device for horizon N = %d, %s (got %d ADMM iterations, "
            "status %d, rho %.10g, error %.3g; expected %d, solved, %.10g, < 1e-8): this build of libqrw_hip.so computes wrong results "
-           "(a code-generation problem seen with non-shipped compiler options, DESIGN.md 6b); rebuild with the Makefile's flags "
+           "(a code-generation problem seen with non-shipped compiler options, docs/HISTORY.md 6b); rebuild with the Makefile's flags "
            "(QRW_SKIP_SELFTEST=1 skips this check)", who, N, kKatModeName[mode], r.iters, r.status, r.rho, r.err, r.want_iters, r.want_rho);
   return fail(-20, msg);
 }

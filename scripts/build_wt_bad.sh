@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/build_wt_bad.sh SHA... : for each commit, a worktree copy under build/wt/SHA with the shipped build and the
-# "bad" build of DESIGN.md 6b (max-ilp + -DQRW_PROFILE_PHASES on mpc_kernel.hip) as libqrw_hip_bad.so
+# "bad" build of docs/HISTORY.md 6b (max-ilp + -DQRW_PROFILE_PHASES on mpc_kernel.hip) as libqrw_hip_bad.so
 set -e
 R=/root/repo
 for sha in "$@"; do

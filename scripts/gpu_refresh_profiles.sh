@@ -23,6 +23,8 @@ cp $(find $OUT/stats32 -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel
 cp $(find $OUT/stats32 -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace_n32.csv
 QRW_PREEMPT_CHUNK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32u -o st -- python3 $R/bench.py --n-steps 32 --gaits walk,trot,bounding --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/stats32u.err
 cp $(find $OUT/stats32u -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_bench_n32_mixed_unsliced.csv
+# the 1:10 control loop's own kernels (control_pre_quad_kernel, wbc16_kernel): 40 iterations at batch 4096
+bash $R/scripts/gpu_loop_profile.sh > $OUT/loopk.log 2>&1 && cp $(find $R/gpurun_out/loopk -name "*kernel_stats.csv" | head -1) $OUT/${ROUND}_kernel_stats_control_loop.csv
 echo "rocprof stats done"
 cd $R
 # counter passes of every bench shape that carries a roofline block (bench.py PMC_SHAPES): headline, config 4, config 2, batch 1

@@ -5,7 +5,7 @@ park, v_accvgpr_read_b32 to fetch: the 72 registers of the Delta^-1 rows, read t
 48 of rarely read scalings).  The compiler allocates those AGPRs itself ("=a" / "a" constraints), may move a parked value
 around a cold high-pressure block (it does, legally, around the factor and the termination-check blocks) and uses the rest
 of the accumulation file as spill space for architectural registers.  The one build of this kernel on record that computed
-wrong results had run out of AGPRs and spilled to scratch while AccD values were live.  Checked per
+wrong results (docs/HISTORY.md 6b) had run out of AGPRs and spilled to scratch while AccD values were live.  Checked per
 mpc_solve_kernel instantiation:
   (a) no scratch_ instruction anywhere in the kernel;
   (b) every AGPR an asm block reads is written by some asm block of the kernel;

@@ -117,7 +117,7 @@ def test_product_never_imports_the_oracle():
 
 def test_shipped_mpc_kernel_spills_nothing_to_scratch(tmp_path):
     """The MPC kernel lives at the edge of the register file (256 VGPRs + ~254 AGPRs).  The one build on record that
-    computed wrong results was one in which the allocator ran out of accumulation registers and went to
+    computed wrong results (docs/HISTORY.md 6b) was one in which the allocator ran out of accumulation registers and went to
     scratch while inline-asm-pinned values (AccD) were live; the shipped flags must leave EVERY instantiation with no
     scratch, and the N = 16 one with AGPRs to spare.  On top of the compiler's own resource report, the listing is scanned
     (scripts/isa_accd_scan.py): no scratch instruction, every AGPR the asm blocks read is parked by an asm block, and --

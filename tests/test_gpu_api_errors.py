@@ -326,3 +326,47 @@ def test_two_caller_threads_with_their_own_handles(synth_mod):
         for rep in range(3):
             for a, b in zip(alone[i][rep], both[i][rep]):
                 assert np.array_equal(a, b), (i, rep)
+
+
+def test_one_handle_per_visible_device_stepped_from_one_thread(synth_mod):
+    """Multi-GPU readiness (the batch is sharded over the GPUs of a node, one shard per device): ONE
+    process creates a handle on EVERY visible device and steps them from one thread while torch's current device stays 0 -- every
+    entry point has to switch to its handle's device and back (DeviceScope, qrw_api.hip), the known-answer gate runs per device,
+    and tensors on another device than the handle's are refused.  Every device must return, bit for bit, what device 0 returns for
+    the same shard (same kernels, same arithmetic).  Skips on a box with one GPU: the first multi-GPU box that runs the suite
+    exercises it."""
+    import torch
+
+    import qrw_hip
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one visible device: DeviceScope's switch has nothing to switch to")
+    n_dev = min(n_dev, 6)  # (the pool's process guard: at most 6 of a user's processes / contexts on one box's cards)
+    B, N, S = 64, 16, 3
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot", "walk"), seed0=717000)
+    steps = [sb.step(s) for s in range(S)]
+    keys = ("xref", "fsteps", "q", "dq", "contacts", "pgoals", "vgoals", "agoals")
+    engs = [qrw_hip.Batch(B, N, device=d) for d in range(n_dev)]
+    assert torch.cuda.current_device() == 0
+    outs = [[] for _ in range(n_dev)]
+    for s in range(S):
+        for d in range(n_dev):  # interleaved: the current device never changes on the caller's side
+            t = {k: torch.from_numpy(np.ascontiguousarray(steps[s][k])).to("cuda:%d" % d) for k in keys}
+            o = engs[d].mpc_solve(t["xref"], t["fsteps"], s)
+            w = engs[d].wbc_compute(t["q"], t["dq"], o[:, 12:, 0].contiguous(), t["contacts"], t["pgoals"], t["vgoals"], t["agoals"])
+            outs[d].append((o, w["tau_ff"]))
+            assert torch.cuda.current_device() == 0 and o.device.index == d
+    for d in range(n_dev):
+        torch.cuda.synchronize(d)
+    for d in range(1, n_dev):
+        for s in range(S):
+            assert torch.equal(outs[d][s][0].cpu(), outs[0][s][0].cpu()) and torch.equal(outs[d][s][1].cpu(), outs[0][s][1].cpu()), (d, s)
+        assert np.array_equal(engs[d].mpc_stats()["iters"], engs[0].mpc_stats()["iters"])
+        host = engs[d].mpc_solve_host(steps[0]["xref"], steps[0]["fsteps"], 0)  # the _host path on device d, current device 0
+        assert np.array_equal(host, outs[0][0][0].cpu().numpy()) and torch.cuda.current_device() == 0
+    with pytest.raises(qrw_hip.QrwError):  # a tensor of device 0 handed to device 1's handle
+        engs[1].mpc_solve(torch.zeros((B, 12, N + 1), dtype=torch.float64, device="cuda:0"),
+                          torch.zeros((B, 20, 12), dtype=torch.float64, device="cuda:0"), 0)
+    for e in engs:
+        e.close()
