@@ -88,6 +88,8 @@ def load(fast=False):
         "wbc_oracle_destroy": (None, [vp]),
         "wbc_oracle_compute": (C.c_int, [vp] + [_dp] * 12),
         "wbc_oracle_qp_iter": (C.c_int, [vp]),
+        "wbc_oracle_qp_status": (C.c_int, [vp]),
+        "wbc_oracle_qp_rho": (C.c_double, [vp]),
         "wbc_oracle_get_feet": (None, [vp, _dp, _dp, _dp]),
         "wbc_oracle_get_k_since_contact": (None, [vp, _dp]),
         "planner_oracle_create": (vp, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
@@ -388,6 +390,13 @@ class WbcBatch:
         for h in getattr(self, "_hs", []):
             self._lib.wbc_oracle_destroy(h)
         self._hs = []
+
+    def qp_stats(self):
+        """(ADMM iteration counts, statuses, rho) of the box-QPs of the last compute, per instance (tests only)."""
+        it = np.array([self._lib.wbc_oracle_qp_iter(h) for h in self._hs], dtype=np.int32)
+        st = np.array([self._lib.wbc_oracle_qp_status(h) for h in self._hs], dtype=np.int32)
+        rho = np.array([self._lib.wbc_oracle_qp_rho(h) for h in self._hs])
+        return it, st, rho
 
     def compute(self, q, dq, f_cmd, contacts, pgoals, vgoals, agoals, threads):
         B = self.B

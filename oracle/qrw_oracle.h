@@ -101,6 +101,8 @@ int wbc_oracle_compute(wbc_oracle *o, const double *q, const double *dq, const d
                        const double *pgoals, const double *vgoals, const double *agoals, double *tau_ff, double *qdes,
                        double *vdes, double *f_with_delta, double *ddq_res);
 int wbc_oracle_qp_iter(const wbc_oracle *o);
+int wbc_oracle_qp_status(const wbc_oracle *o); /* tests only */
+double wbc_oracle_qp_rho(const wbc_oracle *o);  /* tests only */
 void wbc_oracle_get_feet(const wbc_oracle *o, double *feet_pos3x4, double *feet_err3x4, double *feet_vel3x4);
 void wbc_oracle_get_k_since_contact(const wbc_oracle *o, double *k4);
 

@@ -367,6 +367,8 @@ int wbc_oracle_compute(wbc_oracle *o, const double *q, const double *dq, const d
 }
 
 int wbc_oracle_qp_iter(const wbc_oracle *o) { return qpwbc_oracle_iter(o->box_qp); }
+int wbc_oracle_qp_status(const wbc_oracle *o) { return qpwbc_oracle_status(o->box_qp); }
+double wbc_oracle_qp_rho(const wbc_oracle *o) { return qpwbc_oracle_rho(o->box_qp); }
 void wbc_oracle_get_feet(const wbc_oracle *o, double *p, double *e, double *v) {
   if (p) memcpy(p, o->feet_pos, sizeof(o->feet_pos));
   if (e) memcpy(e, o->feet_err, sizeof(o->feet_err));

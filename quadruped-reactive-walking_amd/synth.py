@@ -372,3 +372,56 @@ class RandomContactTables:
             xref[b, 2, 1:] = H_REF
             xref[b, 11, 1:] = wz
         return dict(xref=xref, fsteps=fsteps, gait=gait)
+
+
+class RandomWbcInputs:
+    """Seeded WBC inputs far outside what the periodic-gait controller produces, for parity tests and soaks of the whole-body
+    step (scripts/QP_WBC.py:52-131 takes ANY q / dq / f_cmd / contacts / goals): arbitrary base orientation (a random unit
+    quaternion in a fifth of the calls, up to +-0.6 rad about a random axis otherwise), base offsets, joint angles +-0.6 rad
+    around the nominal pose (knees kept >= 0.25 rad from straight: the InvKin's 3x3 foot Jacobian is singular there, as in the
+    reference), joint velocities up to 6 rad/s, a base twist up to 1.5; contact sets that persist and flip at random (all 16
+    occur, so k_since_contact and its 1/16-ramp of the foot tracking gains move); commanded forces that VIOLATE the QP's bounds
+    in a third of the stance feet (f_z up to 32 N > 25, tangential up to 1.3 f_z > mu f_z), occasionally non-zero on swing feet;
+    foot goals up to 5 cm / 1 m/s / 10 m/s^2 from the feet.  step(c) -> dict(q, dq, f_cmd, contacts, pgoals, vgoals, agoals)."""
+
+    def __init__(self, B, seed0=20700000, b0=0):
+        self.B = B
+        self.rng = [np.random.default_rng(seed0 + b0 + b) for b in range(B)]
+        self.contacts = np.ones((B, 4))
+
+    def step(self, c):
+        B = self.B
+        q, dq = np.zeros((B, 19)), np.zeros((B, 18))
+        f, pg, vg, ag = np.zeros((B, 12)), np.zeros((B, 3, 4)), np.zeros((B, 3, 4)), np.zeros((B, 3, 4))
+        for b in range(B):
+            r = self.rng[b]
+            flip = r.random(4) < (1.0 if c == 0 else 0.3)
+            new = (r.random(4) < 0.6).astype(np.float64)
+            self.contacts[b] = np.where(flip, new, self.contacts[b])
+            q[b, :3] = r.uniform(-0.3, 0.3, 3) + np.array([0, 0, H_REF])
+            if r.random() < 0.2:
+                quat = r.normal(size=4)
+            else:
+                axis = r.normal(size=3)
+                ang = r.uniform(-0.6, 0.6)
+                quat = np.concatenate([np.sin(ang / 2) * axis / np.linalg.norm(axis), [np.cos(ang / 2)]])
+            q[b, 3:7] = quat / np.linalg.norm(quat)
+            qj = Q_NOMINAL + r.uniform(-0.6, 0.6, 12)
+            knee = qj[2::3]
+            qj[2::3] = np.where(np.abs(knee) < 0.25, np.sign(Q_NOMINAL[2::3]) * 0.25, knee)
+            q[b, 7:] = qj
+            dq[b, :6] = r.uniform(-1.5, 1.5, 6)
+            dq[b, 6:] = r.uniform(-6.0, 6.0, 12)
+            ct = self.contacts[b]
+            fz = r.uniform(0.0, 24.0, 4)
+            viol = r.random(4) < 0.33
+            fz = np.where(viol, r.uniform(20.0, 32.0, 4), fz)
+            tang = np.where(viol, 1.3, 0.6)
+            fx, fy = r.uniform(-1, 1, 4) * tang * fz, r.uniform(-1, 1, 4) * tang * fz
+            on = ct if r.random() < 0.9 else np.ones(4)  # now and then forces on swing feet too
+            f[b, 0::3], f[b, 1::3], f[b, 2::3] = fx * on, fy * on, fz * on
+            feet = leg_fk(qj[None])[0]  # (4,3) in the base frame of the fixed-base model
+            pg[b] = feet.T + r.uniform(-0.05, 0.05, (3, 4))
+            vg[b] = r.uniform(-1.0, 1.0, (3, 4)) * (1 - ct)[None, :]
+            ag[b] = r.uniform(-10.0, 10.0, (3, 4)) * (1 - ct)[None, :]
+        return dict(q=q, dq=dq, f_cmd=f, contacts=self.contacts.copy(), pgoals=pg, vgoals=vg, agoals=ag)

@@ -1,7 +1,9 @@
 """Soak of the MPC kernels against the CPU oracle on ARBITRARY contact tables (synth.RandomContactTables; the suite's form is
 tests/test_gpu_mpc_random_tables.py).  Per (N, B, K[, full]) block: K warm-started calls of B instances; every solve must take
 the oracle's iteration count and status and match its result to 1e-4.  A mismatch is printed with the (seed0, instance, call)
-that reproduces it.  usage: gpu_soak_random_tables.py [N:B:K[:full] ...]   (default: >= 50 000 solves in total)"""
+that reproduces it.  usage: gpu_soak_random_tables.py [N:B:K[:full] | wbc:B:K ...]   (default: >= 50 000 MPC solves in total)
+A `wbc:B:K` block soaks the whole-body step on synth.RandomWbcInputs the same way (QP iteration counts, torques, q_des / v_des, forces).
+QRW_SOAK_SEED shifts every block's seeds (several runs = several independent samples)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "quadruped-reactive-walking_amd"), os.path.join(ROOT, "oracle")]
@@ -13,12 +15,51 @@ threads = max(1, min(16, len(os.sched_getaffinity(0))))
 total = bad_it = bad_st = bad_res = 0
 worst_all = 0.0
 t_start = time.time()
+seed_shift = int(os.environ.get("QRW_SOAK_SEED", "0")) * 1000003
+wbc_total = wbc_bad = 0
+wbc_worst = 0.0
 for spec in blocks:
     p = spec.split(":")
+    if p[0] == "wbc":
+        B, K = int(p[1]), int(p[2])
+        gen = synth.RandomWbcInputs(B, seed0=40000000 + seed_shift)
+        eng = qrw_hip.Batch(B)
+        oracle.build(fast=True)
+        # two builds of the oracle (strict IEEE / -O3 -march=native): a robot whose two oracle results disagree (rho or any output
+        # beyond 1e-9, or the iteration count) at this or an earlier call is ROUNDING-SENSITIVE -- OSQP's adaptive rho taken from a
+        # residual that has converged to noise, tests/test_gpu_wbc.py::test_wbc_on_wild_inputs_matches_oracle -- and held to 1e-2 /
+        # one termination check; every other robot to the iteration count and 1e-4
+        ref, ref2 = oracle.WbcBatch(B, 0.002, fast=False), oracle.WbcBatch(B, 0.002, fast=True)
+        sens = np.zeros(B, bool)
+
+        def dev(x, y):
+            e = np.zeros(B)
+            for u, v in zip(x, y):
+                e = np.maximum(e, np.abs(u - v).reshape(B, -1).max(1) / np.maximum(np.abs(v).reshape(B, -1).max(1), 1e-12))
+            return np.where(np.isnan(e), np.inf, e)
+
+        for c in range(K):
+            d = gen.step(c)
+            args = (d["q"], d["dq"], d["f_cmd"], d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+            o = eng.wbc_compute_host(*args)
+            ra, rb = ref.compute(*args, threads), ref2.compute(*args, threads)
+            (it, sto, rho), (it2, _, rho2) = ref.qp_stats(), ref2.qp_stats()
+            st = eng.wbc_stats()
+            sens |= (dev(rb, ra) > 1e-9) | (it != it2) | (np.abs(rho2 / rho - 1) > 1e-9)
+            e = dev((o["tau_ff"], o["qdes"], o["vdes"], o["f_with_delta"]), ra)
+            m = np.where(sens, (np.abs(st["iters"] - it) > 25) | (e >= 1e-2), (it != st["iters"]) | (e >= 1e-4)) | (st["status"] != sto)
+            for b in np.nonzero(m)[0][:5]:
+                print("MISMATCH wbc: seed0=%d instance %d call %d: hip iters %d status %d, oracle iters %d status %d, rel err %.3e, sensitive %s"
+                      % (40000000 + seed_shift, b, c, st["iters"][b], st["status"][b], it[b], sto[b], e[b], sens[b]), flush=True)
+            wbc_bad += int(m.sum()); wbc_total += B
+            wbc_worst = max(wbc_worst, float(e[~sens].max()))
+            print("WBC call %d: %d steps, %d robots rounding-sensitive so far; worst rel err %.2e on the others (iteration counts equal), %.2e on the sensitive ones; "
+                  "QP iterations %d..%d; so far %d steps, %d mismatches" % (c, B, int(sens.sum()), e[~sens].max(), e[sens].max() if sens.any() else 0.0, it.min(), it.max(), wbc_total, wbc_bad), flush=True)
+        continue
     N, B, K = int(p[0]), int(p[1]), int(p[2])
     full = len(p) > 3
     NG = N if full else max(20, N + 4)
-    seed0 = 30000000 + 100000 * N + (50000 if full else 0)
+    seed0 = 30000000 + 100000 * N + (50000 if full else 0) + seed_shift
     gen = synth.RandomContactTables(B, N, N_gait=NG, seed0=seed0)
     eng = qrw_hip.Batch(B, n_steps=N, N_gait=NG, T_gait=0.02 * N)
     ref = oracle.MPCBatch(B, 0.02, N, 0.02 * N, NG, fast=False)
@@ -48,4 +89,6 @@ for spec in blocks:
           % (N, NG, B, K, seed0, worst, its_max, sorted(statuses), single), flush=True)
 print("SOAK random contact tables: %d solves, worst rel err %.3e, mismatches: iterations %d, status %d, result (>= 1e-4) %d"
       % (total, worst_all, bad_it, bad_st, bad_res))
-sys.exit(1 if (bad_it or bad_st or bad_res) else 0)
+if wbc_total:
+    print("SOAK wild WBC inputs: %d whole-body steps, worst rel err %.3e on the robots that are not rounding-sensitive, mismatches (QP iterations / status / result) %d" % (wbc_total, wbc_worst, wbc_bad))
+sys.exit(1 if (bad_it or bad_st or bad_res or wbc_bad) else 0)

@@ -416,3 +416,70 @@ def test_wbc16_matches_the_quad_kernel(synth_mod, monkeypatch):
             worst = max(worst, e)
             assert e < 1e-9, (s, key, e)
     print("wbc16 vs quad kernel: worst relative deviation %.2e" % worst)
+
+
+@LANES
+def test_wbc_on_wild_inputs_matches_oracle(oracle_mod, synth_mod, lanes):
+    """The whole-body step far outside what the periodic-gait controller feeds it (synth.RandomWbcInputs: arbitrary base
+    orientation, joints +-0.6 rad around the nominal pose, joint velocities up to 6 rad/s, persistent random contact sets -- all
+    16 --, commanded forces that violate the QP's 25 N bound and its friction cone in a third of the stance feet, forces on
+    swing feet, goals centimetres and m/s away): scripts/QP_WBC.py:52-131 accepts any of it.  Both kernel forms against the
+    oracle over 10 warm-started calls.
+
+    What "parity" can mean here was measured first (scripts/gpu_wbc_wild_study.py, docs/HISTORY.md 8): on these inputs the box-QP
+    runs past OSQP's adaptive-rho test (200 iterations) in a few per cent of the solves, where the primal residual has already
+    converged to rounding noise -- rho * sqrt(primal / dual ratio) then differs at 1e-4 ... 1e-2 relative between TWO BUILDS OF
+    THE SAME ORACLE SOURCE (strict IEEE against -O3 -march=native), rho persists, and every later warm-started solve of that robot
+    differs at 1e-6 ... 1e-3 (all inside the QP's own 1e-5 tolerances): the reference built twice would do the same.  So both oracle
+    builds run beside the kernel; a robot counts as ROUNDING-SENSITIVE from the first call on at which the two builds disagree
+    (rho or any output beyond 1e-9, or the iteration count).  Every other robot must take the oracle's iteration count and match
+    it to 1e-4 (measured <= 4e-9); a sensitive one must stay within 1e-2 and one termination check (25 iterations); status solved
+    and k_since_contact exact for all.  At least 70 % of the robots must still be insensitive after the ten calls."""
+    import qrw_hip
+
+    B, K = 144, 10
+    gen = synth_mod.RandomWbcInputs(B, seed0=20700000 + lanes)
+    eng = qrw_hip.Batch(B)
+    eng.wbc_set_lanes(lanes)
+    oracle_mod.build(fast=True)
+    ref, ref2 = oracle_mod.WbcBatch(B, 0.002, fast=False), oracle_mod.WbcBatch(B, 0.002, fast=True)
+    threads = max(1, min(16, len(__import__("os").sched_getaffinity(0))))
+    dp = __import__("ctypes").POINTER(__import__("ctypes").c_double)
+
+    def dev(x, y):
+        e = np.zeros(B)
+        for u, v in zip(x, y):
+            e = np.maximum(e, np.abs(u - v).reshape(B, -1).max(1) / np.maximum(np.abs(v).reshape(B, -1).max(1), 1e-12))
+        return e
+
+    pats, bound, its = set(), 0, []
+    sensitive = np.zeros(B, bool)
+    worst_clean = worst_sens = 0.0
+    for c in range(K):
+        d = gen.step(c)
+        args = (d["q"], d["dq"], d["f_cmd"], d["contacts"], d["pgoals"], d["vgoals"], d["agoals"])
+        o = eng.wbc_compute_host(*args)
+        ra, rb = ref.compute(*args, threads), ref2.compute(*args, threads)
+        (it, st_o, rho), (it2, _, rho2) = ref.qp_stats(), ref2.qp_stats()
+        st = eng.wbc_stats()
+        assert (st["status"] == 1).all() and (st_o == 1).all(), c
+        ksc = np.zeros((B, 4))
+        for b, h in enumerate(ref._hs):
+            ref._lib.wbc_oracle_get_k_since_contact(h, ksc[b].ctypes.data_as(dp))
+        assert np.array_equal(st["k_since_contact"], ksc), c
+        sensitive |= (dev(rb, ra) > 1e-9) | (it != it2) | (np.abs(rho2 / rho - 1) > 1e-9)
+        e = dev((o["tau_ff"], o["qdes"], o["vdes"], o["f_with_delta"]), ra)
+        clean = ~sensitive
+        assert np.array_equal(st["iters"][clean], it[clean]), (c, np.nonzero(clean & (st["iters"] != it))[0][:8])
+        assert (e[clean] < RTOL).all(), (c, np.nonzero(clean & (e >= RTOL))[0][:8], e[clean].max())
+        assert (np.abs(st["iters"][sensitive] - it[sensitive]) <= 25).all() and (e[sensitive] < 1e-2).all(), (c, e[sensitive].max() if sensitive.any() else 0)
+        worst_clean = max(worst_clean, float(e[clean].max()))
+        worst_sens = max(worst_sens, float(e[sensitive].max()) if sensitive.any() else 0.0)
+        pats |= set(map(tuple, d["contacts"].astype(int)))
+        bound += int((ra[3][:, 2::3] > 24.99).sum())
+        its.append(it)
+    its = np.concatenate(its)
+    print("wild WBC inputs, lanes %d: %d of %d robots rounding-sensitive after %d calls (two oracle builds disagree); worst relative "
+          "deviation %.2e on the others, %.2e on the sensitive ones; QP iterations %d..%d, %d contact sets, %d forces on the 25 N bound"
+          % (lanes, int(sensitive.sum()), B, K, worst_clean, worst_sens, its.min(), its.max(), len(pats), bound))
+    assert len(pats) == 16 and its.max() >= 150 and sensitive.mean() <= 0.30
