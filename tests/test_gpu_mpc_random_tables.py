@@ -167,9 +167,9 @@ def _hand_tables(N, N_gait):
         t[k, 3 * j:3 * j + 3] = sh[3 * j:3 * j + 3]
     tabs.append(t)
     # 3: one stance foot whose x is exactly 0 but y is not: reads as swing, the row goes on
-    t = full.copy(); t[2, 0] = 0.0; t[5, 9] = 0.0; tabs.append(t)
+    t = full.copy(); t[min(2, N - 1), 0] = 0.0; t[min(5, N - 1), 9] = 0.0; tabs.append(t)
     # 4: z entries only in one row (x = y = 0 for all feet): not an all-zero row, but an all-zero gait row
-    t = trot.copy(); t[3] = 0.0; t[3, 2::3] = 0.01; tabs.append(t)
+    t = trot.copy(); t[min(3, N - 1)] = 0.0; t[min(3, N - 1), 2::3] = 0.01; tabs.append(t)
     # 5: footholds far from the shoulders, three-stance rows in shuffled order
     t = full.copy()
     for k in range(N):

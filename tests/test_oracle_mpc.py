@@ -394,3 +394,93 @@ def test_full_gait_table_without_a_zero_row_is_defined_behaviour(oracle_mod, syn
                 assert ma[b].iter == mb[b].iter and ma[b].status == mb[b].status == 1
                 assert np.array_equal(ma[b].get_gait(), mb[b].get_gait()[:N])
                 assert np.array_equal(ma[b].get_Sgait(), mb[b].get_Sgait())
+
+
+class StatefulDenseQP:
+    """A second, independently written restatement of how the constraint matrix EVOLVES over warm-started calls
+    (/root/reference/src/MPC.cpp:626-649 run, :686-701 construct_gait, :665-681 construct_S, :213-256 create_ML's value part,
+    :418-464 update_ML): plain numpy, dense, stateful -- the B blocks and S flags of rows the current table does not reach keep
+    whatever earlier calls left there.  Written from the reference's text, not from oracle/mpc_oracle.c."""
+
+    def __init__(self, N, N_gait):
+        self.N, self.N_gait = N, N_gait
+        self.gait = np.zeros((N_gait + 1, 4))      # (+ a guard row: the reference's matrix has N_gait rows, tests/DESIGN.md 2)
+        self.Bang = np.zeros((N, 3, 12))           # rows 9..11 of B_k
+        self.S = np.zeros(12 * N)
+
+    def _bang(self, yaw, levers):
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+        Iinv = np.linalg.inv(R.T @ GI @ R)
+        return np.hstack([DT * (Iinv @ skew(levers[:, i])) for i in range(4)])
+
+    def call(self, num_iter, xref, fsteps):
+        N = self.N
+        k = 0                                       # construct_gait
+        while k < self.N_gait and np.any(fsteps[k] != 0.0):
+            self.gait[k] = (fsteps[k, 0::3] != 0.0)
+            k += 1
+        if k < self.N_gait:
+            self.gait[k] = 0
+        if num_iter == 0:                           # create_ML: default footholds, no CoM offset, every step
+            foot = np.array([[0.19, 0.19, -0.19, -0.19], [0.15005, -0.15005, 0.15005, -0.15005], [0, 0, 0, 0]])
+            for j in range(N):
+                self.Bang[j] = self._bang(xref[5, j], foot - xref[0:3, j:j + 1])
+            self.S[:] = 0.0
+        else:                                       # update_ML: rows until the first all-zero GAIT row
+            j = 0
+            while np.any(self.gait[j]):
+                levers = fsteps[j].reshape(4, 3).T - (xref[0:3, j:j + 1] + np.array([[0], [0], [-0.03]]))
+                self.Bang[j] = self._bang(xref[5, j], levers)
+                j += 1
+        i = 0                                       # construct_S
+        while np.any(self.gait[i]):
+            self.S[12 * i:12 * i + 12] = np.repeat(1.0 - self.gait[i], 3)
+            i += 1
+        # the dense matrix: the constant part from dense_qp (full-stance dummy table), then the stateful values
+        dummy = np.ones((self.N_gait, 12))
+        A, l, u, Pd = dense_qp(xref, dummy, N, first_call=True)
+        for j in range(N):
+            A[12 * j + 9:12 * j + 12, 12 * (N + j):12 * (N + j) + 12] = self.Bang[j]
+            for e in range(12):
+                A[12 * N + 12 * j + e, 12 * (N + j) + e] = self.S[12 * j + e]
+        return A, l, u, Pd
+
+
+@pytest.mark.parametrize("N,full", [(5, False), (16, False), (24, False), (16, True), (12, False)])
+def test_qp_assembly_on_arbitrary_contact_tables(oracle_mod, synth_mod, N, full):
+    """The oracle's matrix values, bounds and getters over warm-started calls on ARBITRARY contact tables
+    (synth.RandomContactTables: tables of any length that change completely between calls, so stale rows matter) and on the
+    hand-made decoding corners of tests/test_gpu_mpc_random_tables.py (a footstep row whose x entries are all 0 but which is
+    not all zero ends update_ML / construct_S and not construct_gait; a stance foot with x = 0 reads as swing; z-only rows),
+    against StatefulDenseQP -- the pin that the wide GPU parity tests' oracle is right about them."""
+    import test_gpu_mpc_random_tables as wide
+
+    N_gait = N if full else max(20, N + 4)
+    Bn = 6
+    gen = synth_mod.RandomContactTables(Bn, N, N_gait=N_gait, seed0=4242 + N)
+    hand = wide._hand_tables(N, N_gait)
+    mpc = [oracle_mod.MPC(DT, N, DT * N, N_gait) for _ in range(Bn)]
+    ind = [StatefulDenseQP(N, N_gait) for _ in range(Bn)]
+    stale_seen = 0
+    for c in range(7):
+        d = gen.step(c)
+        for b in range(Bn):
+            fsteps = d["fsteps"][b]
+            if not full and c in (2, 5):
+                fsteps = hand[(b + c) % hand.shape[0]]
+            xref = d["xref"][b]
+            assert mpc[b].run(c, xref, fsteps) == 0
+            (p, i, x), _, lo, up = mpc[b].qp()
+            A = csc_to_dense(p, i, x, 44 * N, 24 * N)
+            A_ref, l_ref, u_ref, _ = ind[b].call(c, xref, fsteps)
+            assert np.allclose(A, A_ref, rtol=1e-12, atol=1e-15), (c, b, np.abs(A - A_ref).max())
+            assert np.allclose(up, u_ref, rtol=1e-12, atol=1e-14)
+            fin = np.isfinite(l_ref)
+            assert np.array_equal(np.isinf(lo), ~fin) and np.allclose(lo[fin], l_ref[fin], rtol=1e-12, atol=1e-14)
+            assert np.array_equal(mpc[b].get_gait(), ind[b].gait[:N_gait]), (c, b)
+            assert np.array_equal(mpc[b].get_Sgait().ravel(), ind[b].S), (c, b)
+            # did this call leave rows stale that a plain rewrite from the table would have changed?
+            fresh = np.repeat(1.0 - (fsteps[:N, 0::3] != 0), 3, axis=1).ravel()
+            stale_seen += int((fresh != ind[b].S).any())
+    assert stale_seen == 0 if full else stale_seen > 5  # (a full table rewrites every row; the ragged ones really leave rows stale)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from osqp_numpy import OSQPNumpy
-from test_oracle_mpc import DT, dense_qp
+from test_oracle_mpc import DT, StatefulDenseQP, dense_qp
 from test_oracle_wbc import G_matrix
 
 F32 = lambda v: float(np.float32(v))  # noqa: E731  (the reference writes several settings as float literals)
@@ -47,6 +47,39 @@ def test_mpc_iterate_sequence_matches_second_implementation(oracle_mod, synth_mo
         assert np.allclose(second.x, xi, rtol=1e-7, atol=1e-9) and np.allclose(second.y, yi, rtol=1e-7, atol=1e-9)
         x0 = m.get_latest_result()[:12, 0][None]
     assert max(iters) >= 200  # the sequence crossed an adaptive-rho test, not just first-check terminations
+
+
+@pytest.mark.parametrize("N,seed", [(8, 5), (12, 11)])
+def test_mpc_iterate_sequence_on_arbitrary_contact_tables(oracle_mod, synth_mod, N, seed):
+    """The same comparison on ARBITRARY contact tables (synth.RandomContactTables: single-stance rows, ragged tables that change
+    completely between warm-started calls, large state errors -- several adaptive-rho updates per solve): the oracle's solver
+    against the second implementation fed by the second, stateful assembly (StatefulDenseQP), so that neither the matrices nor
+    the ADMM of the wide GPU parity tests' checker stand alone.  rho to 1e-6 here: on these inputs the adapted rho of two builds
+    of one source already differs by ~1e-7 (tests/test_gpu_mpc_random_tables.py)."""
+    gen = synth_mod.RandomContactTables(1, N, seed0=seed)
+    m = oracle_mod.MPC(DT, N, DT * N, gen.N_gait)
+    ind = StatefulDenseQP(N, gen.N_gait)
+    second = None
+    iters = []
+    for s in range(5):
+        d = gen.step(s)
+        xref, fsteps = d["xref"][0], d["fsteps"][0]
+        assert m.run(s, xref, fsteps) == 0
+        A, lo, up, Pd = ind.call(s, xref, fsteps)
+        if second is None:
+            second = OSQPNumpy(np.diag(Pd), np.zeros(24 * N), A, lo, up, sigma=F32(1e-6), eps_abs=F32(1e-6),
+                               eps_rel=F32(1e-6), eps_prim_inf=F32(1e-5), eps_dual_inf=F32(1e-4), alpha=F32(1.6),
+                               adaptive_rho=True, adaptive_rho_interval=200, adaptive_rho_tolerance=F32(5.0))
+        else:
+            second.update_A(A)
+            second.update_bounds(lo, up)
+        sx, _ = second.solve()
+        iters.append(second.iter)
+        assert (second.iter, second.status) == (m.iter, m.status), (s, second.iter, m.iter, second.status, m.status)
+        assert np.isclose(second.rho, m.rho, rtol=1e-6), (s, second.rho, m.rho)
+        sol = m.solution()
+        assert np.abs(sx - sol).max() <= 1e-7 * max(1.0, np.abs(sol).max()), (s, np.abs(sx - sol).max())
+    assert max(iters) >= 400
 
 
 def _wbc_qp(M, Jc, f_cmd, RNEA):
