@@ -433,6 +433,9 @@ int mpc_oracle_restart(mpc_oracle *o, double rho) { return o->work ? oq_restart(
 int mpc_oracle_iter(const mpc_oracle *o) { return o->work ? oq_info_iter(o->work) : -1; }
 int mpc_oracle_status(const mpc_oracle *o) { return o->work ? oq_info_status(o->work) : OQ_UNSOLVED; }
 double mpc_oracle_rho(const mpc_oracle *o) { return o->work ? oq_info_rho(o->work) : 0.0; }
+void mpc_oracle_check_ratios(const mpc_oracle *o, double *out4) {
+  if (o->work) oq_info_check_ratios(o->work, out4); else for (int i = 0; i < 4; i++) out4[i] = 0.0;
+}
 double mpc_oracle_pri_res(const mpc_oracle *o) { return o->work ? oq_info_pri_res(o->work) : 0.0; }
 double mpc_oracle_dua_res(const mpc_oracle *o) { return o->work ? oq_info_dua_res(o->work) : 0.0; }
 int mpc_oracle_nnz_ML(const mpc_oracle *o) { return o->ML.p ? o->ML.p[o->ML.n] : 0; }

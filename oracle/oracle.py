@@ -62,6 +62,7 @@ def load(fast=False):
         "mpc_oracle_status": (C.c_int, [vp]),
         "mpc_oracle_rho": (C.c_double, [vp]),
         "mpc_oracle_pri_res": (C.c_double, [vp]),
+        "mpc_oracle_check_ratios": (None, [vp, _dp]),
         "mpc_oracle_dua_res": (C.c_double, [vp]),
         "mpc_oracle_nnz_ML": (C.c_int, [vp]),
         "mpc_oracle_get_ML": (None, [vp, _ip, _ip, _dp]),
@@ -369,6 +370,15 @@ class MPCBatch:
         it = np.array([self._lib.mpc_oracle_iter(h) for h in self._hs], dtype=np.int32)
         st = np.array([self._lib.mpc_oracle_status(h) for h in self._hs], dtype=np.int32)
         return it, st
+
+    def check_ratios(self):
+        """(B,4): residual / tolerance of the LAST full termination check of every instance's last solve ({primal, dual}) and of
+        the check BEFORE it -- how close to OSQP's threshold a termination decision was (tests: a solve that another arithmetic
+        ends one check earlier or later is a rounding matter exactly when the deciding ratio is within ~1e-3 of 1)."""
+        out = np.zeros((self.B, 4))
+        for b, h in enumerate(self._hs):
+            self._lib.mpc_oracle_check_ratios(h, _ptr(out[b]))
+        return out
 
     def run(self, num_iter, xref, fsteps, threads):
         ni = np.ascontiguousarray(np.broadcast_to(np.asarray(num_iter, np.int32), (self.B,)))

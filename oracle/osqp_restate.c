@@ -37,6 +37,9 @@ struct oq_work {
   double *sol_x, *sol_y;
   int iter, status, rho_updates;
   double pri_res, dua_res, rho_estimate, obj_val;
+  /* test instrumentation (not OSQP): residual / tolerance of the last two full termination checks -- how close to the
+   * threshold a termination decision was.  {primal, dual} of the last check, then of the one before it. */
+  double chk_ratio[4];
   /* linear system: banded Cholesky of K = P + sigma I + A' diag(rho) A */
   int *perm;  /* perm[col] = position in the elimination order */
   int bw;     /* half bandwidth under perm */
@@ -611,7 +614,7 @@ static void update_info(oq_work *w, int iter) {
 }
 
 static int check_termination(oq_work *w, int approximate) {
-  double eps_prim, eps_dual, eps_prim_inf, eps_dual_inf, eps_abs, eps_rel;
+  double eps_prim = 1.0, eps_dual, eps_prim_inf, eps_dual_inf, eps_abs, eps_rel;
   int exitflag = 0, prim_res_check = 0, dual_res_check = 0, prim_inf_check = 0, dual_inf_check = 0;
 
   eps_abs = w->s.eps_abs;
@@ -641,6 +644,12 @@ static int check_termination(oq_work *w, int approximate) {
     }
   }
   eps_dual = compute_dua_tol(w, eps_abs, eps_rel);
+  if (!approximate) {
+    w->chk_ratio[2] = w->chk_ratio[0];
+    w->chk_ratio[3] = w->chk_ratio[1];
+    w->chk_ratio[0] = (w->m == 0) ? 0.0 : w->pri_res / eps_prim;
+    w->chk_ratio[1] = w->dua_res / eps_dual;
+  }
   if (w->dua_res < eps_dual) {
     dual_res_check = 1;
   } else {
@@ -877,6 +886,7 @@ int oq_solve(oq_work *w) {
   double *tmp;
 
   if (!w->s.warm_start) cold_start(w);
+  for (int i = 0; i < 4; i++) w->chk_ratio[i] = 0.0; /* (test instrumentation) */
 
   for (iter = 1; iter <= w->s.max_iter; iter++) {
     tmp = w->x; w->x = w->x_prev; w->x_prev = tmp; /* swap_vectors */
@@ -922,6 +932,9 @@ int oq_restart(oq_work *w, double rho) {
 
 int oq_info_iter(const oq_work *w) { return w->iter; }
 int oq_info_status(const oq_work *w) { return w->status; }
+void oq_info_check_ratios(const oq_work *w, double out4[4]) {
+  for (int i = 0; i < 4; i++) out4[i] = w->chk_ratio[i];
+}
 double oq_info_pri_res(const oq_work *w) { return w->pri_res; }
 double oq_info_dua_res(const oq_work *w) { return w->dua_res; }
 double oq_info_rho(const oq_work *w) { return w->s.rho; }

@@ -85,6 +85,7 @@ const double *oq_solution_y(const oq_work *w);
 int oq_info_iter(const oq_work *w);
 int oq_info_status(const oq_work *w);
 double oq_info_pri_res(const oq_work *w);
+void oq_info_check_ratios(const oq_work *w, double out4[4]); /* test instrumentation: residual / tolerance of the last two checks */
 double oq_info_dua_res(const oq_work *w);
 double oq_info_rho(const oq_work *w);
 int oq_info_rho_updates(const oq_work *w);

@@ -48,6 +48,7 @@ int mpc_oracle_iter(const mpc_oracle *o);
 int mpc_oracle_status(const mpc_oracle *o);
 double mpc_oracle_rho(const mpc_oracle *o);
 double mpc_oracle_pri_res(const mpc_oracle *o);
+void mpc_oracle_check_ratios(const mpc_oracle *o, double *out4); /* tests: residual / tolerance of the last two termination checks */
 double mpc_oracle_dua_res(const mpc_oracle *o);
 int mpc_oracle_nnz_ML(const mpc_oracle *o);
 /* copies of the assembled (unscaled) QP, as handed to OSQP: CSC of ML, P diag, bounds */

@@ -25,23 +25,38 @@ def _threads():
     return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
-def check_against_oracle(eng, ref, d, c, out):
-    """run_sequence's assertions (tests/test_gpu_mpc.py:15-40), every instance of one call."""
+def check_against_oracle(eng, ref, d, c, out, parted=None):
+    """run_sequence's assertions (tests/test_gpu_mpc.py:15-40), every instance of one call.
+    parted (bool array, updated in place): instances that have left the comparison because an earlier solve of theirs ended one
+    termination check apart from the oracle's ON A THRESHOLD DECISION -- the oracle's deciding residual / tolerance within 1e-3
+    of 1 at that check (oracle.MPCBatch.check_ratios): the residual is a difference of O(10) terms at 1e-5, so iterates that agree
+    to 1e-10 give residuals that agree to ~1e-4, and another arithmetic may legitimately decide the other way (seen once in
+    ~5e5 soaked solves: 1.00000002).  None of the suite's seeds does it on this hardware; a different GPU or compiler may."""
     r = ref.run(c, d["xref"], d["fsteps"], _threads())
     it, st = ref.iters()
     g = eng.mpc_stats()
-    assert np.array_equal(g["iters"], it), (c, np.nonzero(g["iters"] != it)[0][:8], g["iters"][g["iters"] != it][:8], it[g["iters"] != it][:8])
-    assert np.array_equal(g["status"], st), c
+    B = out.shape[0]
+    if parted is None:
+        parted = np.zeros(B, bool)
+    ratios = ref.check_ratios()
+    top_prev, top_last = np.maximum(ratios[:, 2], ratios[:, 3]), np.maximum(ratios[:, 0], ratios[:, 1])
+    parted |= ((g["iters"] == it - 25) & (top_prev >= 1.0) & (top_prev < 1.0 + 1e-3)) | \
+              ((g["iters"] == it + 25) & (top_last < 1.0) & (top_last > 1.0 - 1e-3))
+    assert parted.sum() <= 1, "more than one threshold decision in one small test: look at it"
+    live = ~parted
+    bad = live & (g["iters"] != it)
+    assert not bad.any(), (c, np.nonzero(bad)[0][:8], g["iters"][bad][:8], it[bad][:8], ratios[bad][:8])
+    assert np.array_equal(g["status"][live], st[live]), c
     rho = np.array([ref._lib.mpc_oracle_rho(h) for h in ref._hs])
     # rho: 1e-9 in run_sequence on the periodic gaits.  On these inputs the adapted rho (rho * sqrt of a ratio of residual
     # norms that are differences of O(10) terms, taken every 200 iterations) moves by up to 1.7e-7 relative between two
     # builds of the SAME oracle source (strict IEEE against -O3 -march=native with FMA contraction: measured on the
     # N = 12 / 24 cases below), and by up to 8e-7 between kernel and oracle -- rounding, not logic: iteration counts and
     # statuses stay identical and results agree to ~1e-7.  Hence 1e-5 here.
-    assert np.allclose(g["rho"], rho, rtol=1e-5, atol=0), (c, np.abs(g["rho"] / rho - 1).max())
-    assert np.array_equal(np.isnan(out), np.isnan(r)), c
+    assert np.allclose(g["rho"][live], rho[live], rtol=1e-5, atol=0), (c, np.abs(g["rho"] / rho - 1)[live].max())
+    assert np.array_equal(np.isnan(out[live]), np.isnan(r[live])), c
     worst = 0.0
-    for b in range(out.shape[0]):
+    for b in np.nonzero(live)[0]:
         e = max(rel_err(out[b, :12], r[b, :12]), rel_err(out[b, 12:], r[b, 12:]))
         assert e < RTOL, (c, b, e)
         worst = max(worst, e)
@@ -71,9 +86,11 @@ def test_random_contact_tables_match_oracle_in_every_launch_form(oracle_mod, syn
     fs = torch.from_numpy(np.stack([s["fsteps"] for s in steps])).to(dev)
     outs, its, stats = [], [], []
     worst, seen = 0.0, set()
+    parted = np.zeros(B, bool)
     for c in range(K):
         out = plain.mpc_solve(xs[c], fs[c], c).cpu().numpy()
-        w, it = check_against_oracle(plain, ref, steps[c], c, out)
+        w, _ = check_against_oracle(plain, ref, steps[c], c, out, parted)
+        it = plain.mpc_stats()["iters"].copy()  # (the launch forms below are compared with the PLAIN launch, bit for bit)
         worst = max(worst, w)
         g = plain.mpc_stats()
         seen |= set(g["status"].tolist())
@@ -198,13 +215,14 @@ def test_gait_rows_that_read_as_all_swing_stop_the_update(oracle_mod, synth_mod,
     eng = qrw_hip.Batch(B, n_steps=N, N_gait=N_gait, T_gait=0.02 * N)
     ref = oracle_mod.MPCBatch(B, 0.02, N, 0.02 * N, N_gait, fast=False)
     refs1 = [oracle_mod.MPC(0.02, N, 0.02 * N, N_gait) for _ in range(B)]
+    parted = np.zeros(B, bool)
     for c in range(6):
         d = sb.step(c)
         fsteps = hand if c in (1, 2, 4) else d["fsteps"]
         if c == 4:
             fsteps = np.roll(hand, 1, axis=0)  # every instance meets another corner under a warm start
         out = eng.mpc_solve_host(d["xref"], fsteps, c)
-        check_against_oracle(eng, ref, dict(xref=d["xref"], fsteps=fsteps), c, out)
+        check_against_oracle(eng, ref, dict(xref=d["xref"], fsteps=fsteps), c, out, parted)
         for b in range(B):
             assert refs1[b].run(c, d["xref"][b], fsteps[b]) == 0
             gait, S = eng.mpc_gait(b)

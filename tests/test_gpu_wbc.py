@@ -447,9 +447,11 @@ def test_wbc_on_wild_inputs_matches_oracle(oracle_mod, synth_mod, lanes):
     dp = __import__("ctypes").POINTER(__import__("ctypes").c_double)
 
     def dev(x, y):
+        # relative to the output's own scale, floored at 1 (N m, rad, rad/s, N): a robot in flight has contact forces of ~1e-6 N
+        # (the QP's tolerance), whose relative deviation means nothing
         e = np.zeros(B)
         for u, v in zip(x, y):
-            e = np.maximum(e, np.abs(u - v).reshape(B, -1).max(1) / np.maximum(np.abs(v).reshape(B, -1).max(1), 1e-12))
+            e = np.maximum(e, np.abs(u - v).reshape(B, -1).max(1) / np.maximum(np.abs(v).reshape(B, -1).max(1), 1.0))
         return e
 
     pats, bound, its = set(), 0, []
