@@ -107,8 +107,11 @@ for spec in blocks:
                   % (N, NG, seed0, b, c, st["iters"][b], it[b], min(st["iters"][b], it[b]),
                      max(ratios[b, 2], ratios[b, 3]) if early[b] else max(ratios[b, 0], ratios[b, 1]), e[b]), flush=True)
         parted |= new_parted
-        # rounding-sensitive instances: the loose criterion (same status, at most two checks apart, 1e-3), reported in the summary
-        loose_bad = sens & ~parted & ((np.abs(st["iters"].astype(np.int64) - it) > 50) | (stat != st["status"]) | (e >= 1e-3))
+        # rounding-sensitive instances: the loose criterion (same status, results within 1e-3), reported in the summary.  Their
+        # iteration counts are NOT bounded: OSQP applies a new rho only if the estimate is beyond 5x / a fifth of the current one, and
+        # an instance whose estimate sits at that threshold takes 650 or 1650 iterations in the oracle ITSELF depending on the last
+        # bits of its inputs (N = 32, seed0 42200027, instance 899, call 3: docs/HISTORY.md 8) -- the kernel took 1650.
+        loose_bad = sens & ~parted & ((stat != st["status"]) | (e >= 1e-3))
         for b in np.nonzero(loose_bad)[0][:5]:
             print("MISMATCH (rounding-sensitive instance, loose criterion): N=%d seed0=%d instance %d call %d: hip iters %d status %d, oracle iters %d status %d, rel err %.3e"
                   % (N, seed0, b, c, st["iters"][b], st["status"][b], it[b], stat[b], e[b]), flush=True)
@@ -132,7 +135,7 @@ for spec in blocks:
 print("SOAK random contact tables: %d solves, worst rel err %.3e, mismatches: iterations %d, status %d, result (>= 1e-4) %d; "
       "borderline terminations (the oracle's deciding residual within 1e-5 of its tolerance, one check apart, reported above): %d; "
       "rounding-sensitive instances (oracle against itself on inputs perturbed by 1e-13: rho moves by > 1e-6) %d, on which the kernel's "
-      "iteration count differed %d times and the loose criterion (status, two checks, 1e-3) failed %d times"
+      "iteration count differed %d times and the loose criterion (status, results within 1e-3) failed %d times"
       % (total, worst_all, bad_it, bad_st, bad_res, borderline, sens_total, sens_flips, bad_loose))
 if wbc_total:
     print("SOAK wild WBC inputs: %d whole-body steps, worst rel err %.3e on the robots that are not rounding-sensitive, mismatches (QP iterations / status / result) %d" % (wbc_total, wbc_worst, wbc_bad))

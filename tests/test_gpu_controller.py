@@ -397,6 +397,69 @@ def test_bound_iteration_equals_the_two_separate_calls():
         qrw_hip._check(fresh._lib.qrw_iteration_step(fresh._handle, 3, x_fs[0].data_ptr(), None), "qrw_iteration_step")
 
 
+def test_two_bound_iterations_of_one_handle_keep_their_own_buffers():
+    """the library keeps ONE binding per handle, Batch.bind_iteration returns independent-looking callables.  An earlier
+    callable must not run on the buffers of a later bind: each callable re-installs its own binding when another bind of the handle
+    came in between -- and a tensor OBJECT that changes storage (`t.data = ...`) is noticed by Controller_batch's bound path.
+    Two callables of one handle bound to DIFFERENT input tensors, stepped alternately, against a second handle stepped with every
+    pointer per call."""
+    import torch
+
+    import qrw_hip
+    from Controller import Controller_batch
+
+    B, N = 40, 16
+    rng = np.random.default_rng(44)
+    a, ref = qrw_hip.Batch(B, N), qrw_hip.Batch(B, N)
+    for e in (a, ref):
+        e.planner_init()
+        e.controller_init(_t(np.tile(Q_INIT, (B, 1))))
+    vref = _t(rng.uniform(-0.3, 0.3, (B, 6)) * np.array([1.0, 0.5, 0, 0, 0, 1.0]))
+    x = np.zeros((B, 24, N))
+    x[:, 2, :], x[:, 14::3, :] = 0.2229, 6.0
+    x_f = _t(x)
+    qf_np = np.zeros((B, 19))
+    qf_np[:, 2], qf_np[:, 6], qf_np[:, 7:] = 0.2229, 1.0, Q_INIT
+
+    def inputs(seed):
+        r = np.random.default_rng(seed)
+        qf = _t(qf_np + np.pad(r.uniform(-0.02, 0.02, (B, 12)), ((0, 0), (7, 0))))
+        vf = torch.zeros((B, 18), dtype=torch.float64, device="cuda")
+        vf[:, :6] = vref
+        return qf, vf, _t(r.uniform(-0.02, 0.02, (B, 3))), _t(r.uniform(-1, 1, (B, 12)))
+
+    sets = [inputs(1), inputs(2)]
+    pre0 = a.control_pre(1, vref, *sets[0][:3], 0, x_f_mpc=x_f, mpc_inputs=False)
+    fc = pre0["feet_cmd"]
+    post0 = a.wbc_compute_result(pre0["q_wbc"], pre0["b_v"], pre0["f_cmd"], pre0["contacts"], fc[0], fc[1], fc[2], sets[0][0], sets[0][3])
+    rp = ref.control_pre(1, vref, *sets[0][:3], 0, x_f_mpc=x_f, mpc_inputs=False)
+    fc = rp["feet_cmd"]
+    rw = ref.wbc_compute_result(rp["q_wbc"], rp["b_v"], rp["f_cmd"], rp["contacts"], fc[0], fc[1], fc[2], sets[0][0], sets[0][3])
+    steps = [a.bind_iteration(pre0, post0, (vref, *sets[i][:3], sets[i][3], 0)) for i in range(2)]  # the second bind replaces the first in the library
+    for k in range(2, 12):
+        i = (k // 2) & 1  # 2,3 -> set 1; 4,5 -> set 0; ...: each callable is used after the other one has been
+        steps[i](k, x_f)
+        rp = ref.control_pre(k, vref, *sets[i][:3], 0, x_f_mpc=x_f, out=rp, mpc_inputs=False)
+        fc = rp["feet_cmd"]
+        rw = ref.wbc_compute_result(rp["q_wbc"], rp["b_v"], rp["f_cmd"], rp["contacts"], fc[0], fc[1], fc[2], sets[i][0], sets[i][3], out=rw)
+        torch.cuda.synchronize()
+        assert torch.equal(post0["result"], rw["result"]) and torch.equal(pre0["q_wbc"], rp["q_wbc"]), k
+    # Controller_batch's bound path: the same tensor object on other storage must be re-bound, not run on the stale address
+    c1, c2 = Controller_batch(B, Q_INIT), Controller_batch(B, Q_INIT)
+    qf, vf, rpy, vs = inputs(3)
+    qf2 = qf.clone()
+    for k in range(6):
+        if k == 4:  # from here on the caller's q tensor lives elsewhere (and the old storage holds garbage)
+            old = qf.data
+            qf.data = qf.data.clone()
+            old.fill_(float("nan"))
+        r1 = c1.compute(vref, qf, vf, rpy, vs)
+        r2 = c2.compute(vref, qf2, vf, rpy, vs)
+        torch.cuda.synchronize()
+        assert torch.equal(r1.q_des, r2.q_des) and torch.equal(r1.tau_ff, r2.tau_ff), k
+        assert bool(torch.isfinite(r1.tau_ff).all())
+
+
 @pytest.mark.parametrize("mode", ["sync", "async_lag2"])
 def test_stream_groups_controller_equals_the_single_handle(mode):
     """Controller_batch(..., groups=2) (Controller_groups: the fleet as two independent stream groups, opt-in) against the
