@@ -733,3 +733,33 @@ def test_large_disturbances_with_saturated_forces(oracle_mod, synth_mod, scale):
         saturated += int((r[:, 14::3, :] > 24.99).sum())
     assert saturated > 50  # the bound is really active in this test
     assert st["iters"].max() >= 1000
+
+
+def test_config5_total_batch_on_one_gpu(synth_mod):
+    """BASELINE config 5's TOTAL size (8 x 4096 = 32 768 robots, N = 16) as ONE shard on one GPU -- the largest batch anybody asks of a
+    handle (1 GB of solver state; sharding.py deals 4096 per GPU): every instance solved, forces of swing feet zero, friction cone
+    and unilaterality respected, and a spread of instances bit-equal to a small-batch run of the same instances (an instance's
+    result does not depend on the batch it sits in, nor on the longest-first block order a batch this size is launched in)."""
+    import qrw_hip
+
+    B, N = 32768, 16
+    sb = synth_mod.SyntheticBatch(B, N, gaits=("trot",), seed0=20260000)
+    eng = qrw_hip.Batch(B, N)
+    idx = np.array([0, 1, 4095, 4096, 12345, 20000, 32767])
+    small = qrw_hip.Batch(len(idx), N)
+    for s in range(3):
+        d = sb.step(s)
+        out = eng.mpc_solve_host(d["xref"], d["fsteps"], s)
+        o2 = small.mpc_solve_host(d["xref"][idx], d["fsteps"][idx], s)
+        assert np.array_equal(out[idx], o2), s
+    st = eng.mpc_stats()
+    assert (st["status"] == 1).all() and (st["iters"] % 25 == 0).all() and np.isfinite(out).all()
+    order, _ = eng.mpc_order()
+    assert np.array_equal(np.sort(order), np.arange(B, dtype=np.int32))
+    f = out[:, 12:, :].transpose(0, 2, 1).reshape(B, N, 4, 3)
+    gait = d["gait"][:, :N]
+    assert np.abs(f[gait == 0]).max() < 1e-3
+    fs = f[gait == 1]
+    mu = np.float64(np.float32(0.9))
+    assert (fs[:, 2] > -1e-3).all() and (fs[:, 2] < 25 + 1e-3).all()
+    assert (np.abs(fs[:, 0]) <= mu * fs[:, 2] + 1e-3).all() and (np.abs(fs[:, 1]) <= mu * fs[:, 2] + 1e-3).all()
