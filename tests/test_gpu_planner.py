@@ -223,3 +223,70 @@ def test_device_resident_control_step_matches_oracle(oracle_mod):
             wbcs[b].compute(q19[b], dq[b], x_f[b][12:, 0], planners[b].gaits()[1][0], pgb, vel, acc)
             assert np.allclose(tau[b], wbcs[b].tau_ff, rtol=1e-4, atol=1e-6), (k, b)
     assert np.isfinite(tau).all()
+
+
+def test_planner_on_wild_inputs_matches_oracle(oracle_mod):
+    """The planners far outside the joystick's range (src/Gait.cpp, FootstepPlanner.cpp, StatePlanner.cpp, FootTrajectoryGenerator.cpp
+    take any q / v / vref / code): arbitrary yaw over +-pi with roll / pitch up to +-0.5 rad, base positions metres from the origin,
+    reference velocities up to 3 m/s and 3 rad/s (the Raibert terms run into their +-L clamp, src/FootstepPlanner.cpp:160-176), measured
+    velocities a metre per second away from the reference, re-drawn every 40 iterations, yaw rate exactly 0 on some robots, and gait
+    codes arriving in bursts (a new code on consecutive iterations, codes during a transition, code 0).  Every output of every
+    iteration against the oracle, 24 robots x 600 iterations."""
+    import torch
+
+    import qrw_hip
+
+    B, N = 24, 16
+    rng = np.random.default_rng(777)
+    eng = qrw_hip.Batch(B, N)
+    eng.planner_init()
+    refs = [oracle_mod.Planner() for _ in range(B)]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    def draw_vref():
+        v = rng.uniform(-1, 1, (B, 6)) * np.array([3.0, 1.5, 0, 0, 0, 3.0])
+        v[::5, 5] = 0.0
+        v[3::7, :2] = 0.0
+        return v
+
+    vref = draw_vref()
+    out = None
+    worst = [0.0] * 6
+    burst = np.zeros(B, np.int64)
+    for k in range(600):
+        if k % 40 == 39:
+            vref = draw_vref()
+        q7 = np.zeros((B, 7))
+        q7[:, :2] = rng.uniform(-5, 5, (B, 2))
+        q7[:, 2] = 0.2229 + rng.uniform(-0.05, 0.05, B)
+        yaw, pitch, roll = rng.uniform(-np.pi, np.pi, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)
+        cy, sy, cp, sp, cr, sr = np.cos(yaw / 2), np.sin(yaw / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(roll / 2), np.sin(roll / 2)
+        q7[:, 3] = sr * cp * cy - cr * sp * sy
+        q7[:, 4] = cr * sp * cy + sr * cp * sy
+        q7[:, 5] = cr * cp * sy - sr * sp * cy
+        q7[:, 6] = cr * cp * cy + sr * sp * sy
+        hv = vref + rng.uniform(-1.0, 1.0, (B, 6)) * np.array([1, 1, 0.3, 0.5, 0.5, 1])
+        code = np.zeros(B, np.int32)
+        for b in range(B):
+            if burst[b] > 0:  # a burst: a code on every iteration for a while
+                code[b] = rng.integers(0, 6)
+                burst[b] -= 1
+            elif rng.random() < 0.02:
+                code[b] = rng.integers(1, 6)
+                burst[b] = rng.integers(0, 4)
+        out = eng.planner_step(k, t(q7), t(hv), t(vref), t(code), out=out)
+        torch.cuda.synchronize()
+        o = {kk: v.cpu().numpy() for kk, v in out.items()}
+        for b in range(B):
+            r = refs[b]
+            r.step(k, q7[b], hv[b], vref[b], int(code[b]))
+            f, tg, otg = r.footsteps()
+            pos, vel, acc, t0s, tsw = r.feet()
+            assert np.array_equal(o["gait"][b], r.gaits()[1]), (k, b)
+            assert np.array_equal(o["contacts"][b], r.gaits()[1][0]), (k, b)
+            for i, (name, got, ref) in enumerate((("xref", o["xref"][b], r.xref()), ("fsteps", o["fsteps"][b], f), ("target", o["target"][b], otg),
+                                                  ("pos", o["feet_pva"][b, 0], pos), ("vel", o["feet_pva"][b, 1], vel), ("acc", o["feet_pva"][b, 2], acc))):
+                err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+                worst[i] = max(worst[i], err)
+                assert err < (1e-9 if i < 3 else 1e-6), (k, b, name, err)
+    print("planner on wild inputs: worst scaled deviation of xref / fsteps / target / foot position / velocity / acceleration: " + " ".join("%.1e" % w for w in worst))
