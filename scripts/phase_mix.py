@@ -4,11 +4,11 @@ import collections, os, re, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(R, "build", "mpc_mark.s")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DQRW_MARK_PHASES",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DQRW_MARK_PHASES", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-pass-failed",
                        "-I" + R + "/include", "-I" + R + "/quadruped-reactive-walking_amd/csrc", "-Wno-unused-value",
                        "-Wno-unused-result", "-Wno-unused-function", R + "/quadruped-reactive-walking_amd/csrc/mpc_kernel.hip", "-o", out])
 txt = open(out).read()
-k = txt[txt.index("_ZN3qrw16mpc_solve_kernelILi1ELb1ELb0EEEvNS_7MpcArgsE:"):]
+k = txt[txt.index("_ZN3qrw16mpc_solve_kernelILi1ELb1ELb0ELb0EEEvNS_7MpcArgsE:"):]
 k = k[:k.index("s_endpgm")]
 names = {9: "loop head (before factor)", 0: "factor", 1: "rhs", 2: "elim_g", 3: "fwd_chain", 4: "middle", 5: "bwd_chain",
          6: "backsub+A+upd", 7: "exit"}
