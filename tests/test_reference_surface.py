@@ -213,3 +213,27 @@ def test_reference_class_attributes_that_callers_can_see_exist():
     _, ours = _class_surface("MPC_Wrapper", "MPC_Wrapper")
     # the shared-memory plumbing of the child process (Value / Array objects) has no counterpart: streams and events instead
     assert ref - ours <= {"newData", "dataIn", "dataOut", "fsteps_future", "running"}, ref - ours
+
+
+def test_fixture_is_what_the_generator_produces():
+    """Build container only (skips where /root/reference is absent, e.g. on the GPU box): the committed fixture is exactly what
+    tests/golden/make_reference_surface.py derives from the reference's files today -- nobody edited it by hand."""
+    import importlib.util
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "scripts")):
+        pytest.skip("the reference is not present here")
+    spec = importlib.util.spec_from_file_location("make_reference_surface", os.path.join(HERE, "golden", "make_reference_surface.py"))
+    gen = importlib.util.module_from_spec(spec)
+    argv, sys_mod = None, __import__("sys")
+    argv, sys_mod.argv = sys_mod.argv, ["make_reference_surface.py", ref]
+    try:
+        spec.loader.exec_module(gen)
+    finally:
+        sys_mod.argv = argv
+    fresh = {"generated_by": "tests/golden/make_reference_surface.py", "reference": "paLeziart/quadruped-reactive-walking", "python": {},
+             "bindings": {"file": "python/gepadd.cpp", "classes": gen.walk_bindings(os.path.join(ref, "python", "gepadd.cpp"))}}
+    for rel, roots in gen.PY_FILES.items():
+        fresh["python"][rel] = gen.walk_python(os.path.join(ref, rel), roots)
+    fresh["definitions"] = {rel: gen.walk_definitions(os.path.join(ref, rel), names) for rel, names in gen.DEFINED.items()}
+    assert json.loads(json.dumps(fresh, sort_keys=True)) == SURFACE
