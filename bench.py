@@ -393,8 +393,14 @@ def main():
             # Controller_batch's default split: one SIMD per wavefront of the loop's kernels (64 compute units at batch 4096), the
             # latency-oriented setting the mode exists for
             out["secondary_ratio_1_10_async"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True)
-            # 32 compute units for the loop's stream: the highest free-running rate, paid for in iteration latency
-            out["secondary_ratio_1_10_async_32cu"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True, loop_cus=32)
+            # 32 compute units for the loop's stream: the highest free-running rate, paid for in iteration latency.  The caller works
+            # on the loop's own stream here (Controller_batch.loop_stream, the recommended use): with a THIRD stream for the caller's
+            # work the figure depends on which hardware queue that stream happens to share -- by rounds 5-6 this process has created
+            # so many streams before this leg that the caller's landed on the MPC stream's queue (7.9 M iterations/s, 3.3 ms worst:
+            # every caller-side copy queued behind the running solve), while the same leg alone in a fresh process measures 12.8 M /
+            # 0.34 ms (scripts/gpu_async_cus.py, docs/HISTORY.md 8).  INTEGRATION.md: GPU_MAX_HW_QUEUES.
+            out["secondary_ratio_1_10_async_32cu"] = device_resident_loop(sb, B, N, N_gait, dev, multiprocessing=True, loop_cus=32,
+                                                                          on_loop_stream=True)
             # two staggered stream groups through compute() (joined on the caller's stream every iteration): what
             # Controller_batch.for_deadline builds for fleets of 1025..2048 robots; opt-in (the default object is one handle:
             # secondary_ratio_1_10 above)
